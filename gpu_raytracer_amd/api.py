@@ -1,0 +1,165 @@
+"""ctypes binding of librt_hip.so (the C ABI in include/rt_hip.h).
+
+This is the stub a host-language binding would look like (see INTEGRATION.md for the
+Rust `extern "C"` version).  There is no fallback: if the library is missing, or no HIP
+device is present, the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import types as T
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librt_hip.so")
+
+RT_OK = 0
+ERRORS = {-1: "RT_ERR_BAD_ARG", -2: "RT_ERR_OOM", -3: "RT_ERR_HIP", -4: "RT_ERR_NOT_UPLOADED", -5: "RT_ERR_INTERNAL"}
+MODE_LEGACY, MODE_WAVEFRONT, MODE_EXTENDED = 0, 1, 2
+FLAG_COUNTERS = 1
+
+# every symbol include/rt_hip.h declares
+ABI_SYMBOLS = [
+    "rt_create", "rt_upload_scene", "rt_upload_scene_packed", "rt_render", "rt_dispatch_tile",
+    "rt_read_rgb32f", "rt_read_rgba8_channels", "rt_read_rgba8_combined", "rt_read_hits",
+    "rt_get_stats", "rt_last_error", "rt_destroy", "rt_version",
+]
+
+
+class RtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"{ERRORS.get(code, code)}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Load librt_hip.so; raises if the HIP extension has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with `python -m gpu_raytracer_amd.build` "
+                              "(there is no CPU fallback for the hot path)")
+        lib = C.CDLL(LIB_PATH)
+        lib.rt_last_error.restype = C.c_char_p
+        lib.rt_last_error.argtypes = [C.c_void_p]
+        lib.rt_version.restype = C.c_char_p
+        lib.rt_destroy.restype = None
+        lib.rt_destroy.argtypes = [C.c_void_p]
+        for name in ABI_SYMBOLS:
+            fn = getattr(lib, name)
+            if name not in ("rt_last_error", "rt_version", "rt_destroy"):
+                fn.restype = C.c_int
+        _lib = lib
+    return _lib
+
+
+def _p(a):
+    return C.c_void_p(a.ctypes.data) if a is not None and a.size else C.c_void_p(0)
+
+
+class Context:
+    """One rt_ctx.  Mirrors the life cycle RenderState/BufferManager/ComputeRenderer have in the reference."""
+
+    def __init__(self, device_ids=(0,)):
+        self.lib = load()
+        self._h = C.c_void_p(0)
+        ids = (C.c_int * len(device_ids))(*device_ids)
+        rc = self.lib.rt_create(C.byref(self._h), ids, C.c_int(len(device_ids)))
+        if rc != RT_OK:
+            raise RtError(rc, self.lib.rt_last_error(None).decode())
+        self.width = self.height = 0
+
+    def _check(self, rc):
+        if rc != RT_OK:
+            raise RtError(rc, self.lib.rt_last_error(self._h).decode())
+
+    def close(self):
+        if self._h:
+            self.lib.rt_destroy(self._h)
+            self._h = C.c_void_p(0)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- uploads ---------------------------------------------------------------------
+    def upload_scene(self, scene, ref_nodes=None, ref_tri_indices=None):
+        keep = [np.ascontiguousarray(a) for a in (scene.spheres, scene.lights, scene.vertices, scene.triangles, scene.materials)]
+        sp, li, ve, tr, ma = keep
+        rn = np.ascontiguousarray(ref_nodes) if ref_nodes is not None else None
+        ri = np.ascontiguousarray(ref_tri_indices, dtype=np.uint32) if ref_tri_indices is not None else None
+        self._check(self.lib.rt_upload_scene(
+            self._h, _p(sp), C.c_uint32(len(sp)), _p(li), C.c_uint32(len(li)), _p(ve), C.c_uint32(len(ve)),
+            _p(tr), C.c_uint32(len(tr)), _p(ma), C.c_uint32(len(ma)),
+            _p(rn), C.c_uint32(0 if rn is None else len(rn)), _p(ri), C.c_uint32(0 if ri is None else len(ri))))
+
+    def upload_scene_packed(self, metadata, offsets, tri_bufs, triangles_per_buffer, materials):
+        md = np.ascontiguousarray(metadata, dtype=np.uint32)
+        off = np.ascontiguousarray(offsets)
+        bufs = [np.ascontiguousarray(b) for b in tri_bufs]
+        ptrs = (C.c_void_p * 3)(*[b.ctypes.data if b.size else None for b in bufs])
+        counts = (C.c_uint32 * 3)(*[len(b) for b in bufs])
+        ma = np.ascontiguousarray(materials)
+        self._check(self.lib.rt_upload_scene_packed(
+            self._h, _p(md), C.c_size_t(md.size), _p(off), ptrs, counts, C.c_uint32(triangles_per_buffer),
+            _p(ma), C.c_uint32(len(ma))))
+
+    # -- rendering -------------------------------------------------------------------
+    def render(self, width, height, camera, mode=MODE_LEGACY, spp=1, max_bounces=4, frame_seed=0, tile_size=0,
+               tile_rank=0, tile_world=1, counters=False):
+        p = np.zeros((), dtype=T.RENDER_PARAMS)
+        p["camera"] = camera
+        p["width"], p["height"], p["spp"], p["max_bounces"], p["mode"] = width, height, spp, max_bounces, mode
+        p["frame_seed"], p["tile_size"], p["tile_rank"], p["tile_world"] = frame_seed, tile_size, tile_rank, tile_world
+        p["flags"] = FLAG_COUNTERS if counters else 0
+        self._check(self.lib.rt_render(self._h, _p(p)))
+        self.width, self.height = width, height
+        return self.stats()
+
+    def dispatch_tile(self, pc):
+        pcb = np.ascontiguousarray(pc)
+        self._check(self.lib.rt_dispatch_tile(self._h, _p(pcb)))
+        self.width, self.height = int(pcb["resolution"][0]), int(pcb["resolution"][1])
+
+    # -- read-back -------------------------------------------------------------------
+    def read_rgb32f(self):
+        out = np.zeros((self.height, self.width, 3), np.float32)
+        self._check(self.lib.rt_read_rgb32f(self._h, _p(out), C.c_size_t(out.size)))
+        return out
+
+    def read_rgba8_channels(self):
+        outs = [np.zeros((self.height, self.width, 4), np.uint8) for _ in range(3)]
+        self._check(self.lib.rt_read_rgba8_channels(self._h, _p(outs[0]), _p(outs[1]), _p(outs[2]), C.c_size_t(outs[0].size)))
+        return outs
+
+    def read_rgba8_combined(self):
+        out = np.zeros((self.height, self.width, 4), np.uint8)
+        self._check(self.lib.rt_read_rgba8_combined(self._h, _p(out), C.c_size_t(out.size)))
+        return out
+
+    def read_hits(self):
+        prim = np.zeros((self.height, self.width), np.uint32)
+        t = np.zeros((self.height, self.width), np.float32)
+        self._check(self.lib.rt_read_hits(self._h, _p(prim), _p(t), C.c_size_t(prim.size)))
+        return prim, t
+
+    def stats(self):
+        st = np.zeros((), dtype=T.STATS)
+        self._check(self.lib.rt_get_stats(self._h, _p(st)))
+        return {k: st[k].item() for k in st.dtype.names if not k.startswith("_")}
+
+
+def version():
+    return load().rt_version().decode()

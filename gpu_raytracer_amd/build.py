@@ -1,0 +1,40 @@
+"""Builds gpu_raytracer_amd/librt_hip.so for gfx950 with hipcc (in-tree, no JIT cache).
+
+-ffp-contract=off: the kernels keep the reference's f32 operation order (see kernels.hip);
+HIP's default correctly-rounded f32 divide/sqrt is left on.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "librt_hip.so")
+SOURCES = ["kernels.hip", "rt_api.cpp", "bvh_builder.cpp", "rt_host_api.cpp"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
+         "-Wall", "-Wno-unused-function", "-pthread", "-I" + os.path.join(HERE, "..", "include")]
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(CSRC, "host", f) for f in os.listdir(os.path.join(CSRC, "host"))]
+    deps += [os.path.join(HERE, "..", "include", f) for f in ("rt_hip.h", "rt_shared.h")]
+    return any(os.path.isfile(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True, extra=()):
+    if not force and not needs_build():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    cmd = [hipcc] + FLAGS + list(extra) + ["-o", LIB] + srcs
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, extra=[a for a in sys.argv[1:] if a.startswith("-") and a != "--force"])

@@ -1,0 +1,48 @@
+// bvh_builder.h — host-side acceleration-structure build for the HIP layout.
+//
+// The reference builds its BVH with the third-party `bvh` crate (<= 100k triangles,
+// src/bvh.rs:125-151) or in mesh-order chunks of 32+ triangles (> 100k, :154-247) and
+// its kernel neither orders children nor culls by the closest hit
+// (shader/src/bvh.rs:40-85).  Closest-hit results do not depend on topology, so the
+// library builds its own: binned-SAH BVH2, <= 4 triangles per leaf, bounded depth,
+// emitted in the 64-byte two-child-box node layout of device_layout.h.
+#ifndef RT_BVH_BUILDER_H
+#define RT_BVH_BUILDER_H
+
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+#include "device_layout.h"
+
+namespace rt {
+
+struct BuildTri {
+    float v0[3], v1[3], v2[3];
+    uint32_t material_id;
+    uint32_t prim_id;
+};
+
+struct BvhBuild {
+    std::vector<DevNode> nodes;
+    std::vector<DevTri> tris; // leaf order
+    uint32_t root_ref = RT_DEV_LEAF_FLAG; // empty leaf
+    uint32_t depth = 0;                   // inner-node levels on the longest root-to-leaf path
+    uint32_t n_leaves = 0;
+    double sah_cost = 0.0;
+};
+
+struct BvhBuildOptions {
+    int threads = 0;        // 0 = hardware_concurrency
+    uint32_t max_leaf = 4;  // <= RT_DEV_MAX_LEAF_TRIS
+    uint32_t max_depth = RT_DEV_MAX_BVH_DEPTH;
+    float cost_traverse = 1.0f;
+    float cost_intersect = 1.0f;
+};
+
+// Triangles with a non-finite coordinate are dropped: Möller–Trumbore can never accept
+// them (every comparison with NaN fails, shader/src/intersection.rs:109-130).
+void build_bvh(const BuildTri* tris, size_t n, const BvhBuildOptions& opt, BvhBuild& out);
+
+} // namespace rt
+#endif

@@ -1,0 +1,392 @@
+// kernels.hip — gfx950 kernels of the ray-casting hot path.
+//
+// Replaces the reference's rust-gpu kernel `main_cs` (shader/src/lib.rs:25-89) and
+// everything it calls (ray.rs, bvh.rs, intersection.rs, lighting.rs, material.rs,
+// wavefront.rs).  One wavefront (64 lanes) = one 8x8 pixel block; each lane owns a
+// pixel.  All three colour channels are produced in ONE pass: the trace and the
+// lighting are channel independent, only the transmission term of
+// shader/src/lib.rs:323-337 depends on the channel, so the reference's three
+// dispatches per tile (src/compute.rs:184-190) collapse into one.
+//
+// Arithmetic that decides WHICH primitive is hit (ray generation, Möller–Trumbore,
+// sphere quadratic) and the shading keep the reference's f32 operation order; the file
+// is compiled with -ffp-contract=off so nothing is fused implicitly.  The slab test is
+// the reference's own test applied to our boxes plus culling by the closest hit.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_layout.h"
+#include "kernels.h"
+
+#define RT_MIN_RAY_DISTANCE 0.00001f
+#define RT_F32_MAX 3.402823466e+38f
+#define RT_PI 3.14159265358979323846f
+#define WAVE 64
+
+namespace {
+
+struct V3 {
+    float x, y, z;
+};
+__device__ __forceinline__ V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 ld3(const float* p) { return V3{p[0], p[1], p[2]}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ V3 operator/(V3 a, float s) { return v3(a.x / s, a.y / s, a.z / s); }
+__device__ __forceinline__ V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
+// glam scalar-math order: (x*x + y*y) + z*z
+__device__ __forceinline__ float dot(V3 a, V3 b) { return (a.x * b.x) + (a.y * b.y) + (a.z * b.z); }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+    return v3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y);
+}
+__device__ __forceinline__ float length(V3 a) { return sqrtf(dot(a, a)); }
+__device__ __forceinline__ V3 normalize(V3 a) { return a * (1.0f / length(a)); }
+
+// IEEE half round trip, round-to-nearest-even (shader/src/lighting.rs:125-127)
+__device__ __forceinline__ float f16_round_trip(float v) {
+    _Float16 h = (_Float16)v; // v_cvt_f16_f32, RNE in the default mode
+    return (float)h;
+}
+
+struct Hit {
+    float t;
+    uint32_t prim; // RT_PRIM_MISS, RT_PRIM_SPHERE_FLAG | i, or original triangle index
+    uint32_t slot; // index into DevScene::tris for triangle hits
+};
+
+struct Counts {
+    uint32_t nodes, tris;
+};
+
+// ------------------------------------------------------------------------------------
+// Ray generation.  Ray::from_screen_coordinates (shader/src/ray.rs:22-53) for mode 0,
+// generate_camera_ray (shader/src/wavefront.rs:75-112) for mode 1.  fov_scale / aspect /
+// right / true_up are per-frame constants computed on the host in the same order.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void camera_ray(const DevCamera& cam, float sx, float sy, bool wavefront, V3& o, V3& d) {
+    float u = sx / cam.width_f;
+    float v = sy / cam.height_f;
+    float cx = (u * 2.0f - 1.0f) * cam.aspect * cam.fov_scale;
+    float cy = (1.0f - v * 2.0f) * cam.fov_scale;
+    V3 dir = ld3(cam.forward) + ld3(cam.right) * cx + ld3(cam.true_up) * cy;
+    V3 n = normalize(dir);
+    o = ld3(cam.origin);
+    d = wavefront ? n : normalize(n); // Ray::new normalises a second time (ray.rs:14-19)
+}
+
+// ------------------------------------------------------------------------------------
+// Spheres: test_sphere_intersections (shader/src/lib.rs:252-269) +
+// test_sphere_intersection (shader/src/intersection.rs:52-87).  Linear, wave-uniform loop.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void test_spheres(const DevScene& sc, V3 o, V3 d, Hit& hit) {
+    for (uint32_t i = 0; i < sc.n_spheres; i++) {
+        const DevSphere& s = sc.spheres[i];
+        V3 oc = o - ld3(s.center);
+        float a = dot(d, d);
+        float b = 2.0f * dot(oc, d);
+        float c = dot(oc, oc) - s.radius * s.radius;
+        float disc = b * b - 4.0f * a * c;
+        if (disc < 0.0f) continue;
+        float sq = sqrtf(disc);
+        float t1 = (-b - sq) / (2.0f * a);
+        float t2 = (-b + sq) / (2.0f * a);
+        float t = (t1 > RT_MIN_RAY_DISTANCE) ? t1 : t2;
+        if (t > RT_MIN_RAY_DISTANCE && t < hit.t) {
+            hit.t = t;
+            hit.prim = RT_PRIM_SPHERE_FLAG | i;
+            hit.slot = i;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Möller–Trumbore, test_triangle_intersection_direct (shader/src/intersection.rs:91-138),
+// on a pre-gathered DevTri.  Accept 1e-5 < t < closest (strict).  The reference keeps the
+// first triangle found among equal t; its visiting order is its own BVH's.  Here equal t
+// is resolved toward the LOWER original triangle index, which is what the reference's
+// chunked BVH (> 100k triangles, mesh-order leaves visited left to right,
+// src/bvh.rs:154-247) and its brute-force path (shader/src/lib.rs:283) do, and makes the
+// result independent of our own topology.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void test_triangle(const DevTri* __restrict__ tris, uint32_t slot, V3 o, V3 d, Hit& hit) {
+    const float4* p = reinterpret_cast<const float4*>(tris + slot);
+    float4 q0 = p[0], q1 = p[1], q2 = p[2];
+    V3 v0 = v3(q0.x, q0.y, q0.z);
+    V3 e1 = v3(q0.w, q1.x, q1.y);
+    V3 e2 = v3(q1.z, q1.w, q2.x);
+    V3 h = cross(d, e2);
+    float a = dot(e1, h);
+    if (fabsf(a) < RT_MIN_RAY_DISTANCE) return;
+    float f = 1.0f / a;
+    V3 s = o - v0;
+    float u = f * dot(s, h);
+    if (u < 0.0f || u > 1.0f) return;
+    V3 q = cross(s, e1);
+    float v = f * dot(d, q);
+    if (v < 0.0f || u + v > 1.0f) return;
+    float t = f * dot(e2, q);
+    uint32_t prim = __float_as_uint(q2.z);
+    if (t > RT_MIN_RAY_DISTANCE && (t < hit.t || (t == hit.t && prim < hit.prim))) {
+        hit.t = t;
+        hit.prim = prim;
+        hit.slot = slot;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// BVH traversal.  Replaces BvhTraverser::traverse_and_intersect (shader/src/bvh.rs:18-88):
+// per-lane depth-first walk over 64-byte two-child nodes, nearer child first, children
+// whose entry distance exceeds the closest hit are skipped (result-neutral: the reference's
+// slab test ignores the closest hit, shader/src/intersection.rs:151-164, and so visits a
+// superset).  The stack lives in LDS, lane-interleaved (entry k of lane l at
+// stack[k * 64 + l]): ds_read/write_b32 with consecutive lanes on consecutive banks.
+// Depth cannot exceed RT_DEV_STACK_DEPTH: the builder bounds the tree depth.
+// ------------------------------------------------------------------------------------
+template <bool COUNT>
+__device__ __forceinline__ void traverse(const DevScene& sc, V3 o, V3 d, uint32_t* __restrict__ stack, Hit& hit, Counts& cnt) {
+    if (sc.n_tris == 0) return;
+    const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); // ray_aabb_intersect recomputes this per node (:152)
+    const float4* __restrict__ nodes = reinterpret_cast<const float4*>(sc.nodes);
+    uint32_t cur = sc.root_ref;
+    int sp = 0;
+    for (;;) {
+        if (!(cur & RT_DEV_LEAF_FLAG)) {
+            const float4* n = nodes + (size_t)cur * 4;
+            float4 a = n[0], b = n[1], c = n[2], e = n[3];
+            if (COUNT) cnt.nodes++;
+            // ray_aabb_intersect (shader/src/intersection.rs:151-164) on both children
+            float t0x = (a.x - o.x) * inv.x, t0y = (a.y - o.y) * inv.y, t0z = (a.z - o.z) * inv.z;
+            float t1x = (b.x - o.x) * inv.x, t1y = (b.y - o.y) * inv.y, t1z = (b.z - o.z) * inv.z;
+            float u0x = (c.x - o.x) * inv.x, u0y = (c.y - o.y) * inv.y, u0z = (c.z - o.z) * inv.z;
+            float u1x = (e.x - o.x) * inv.x, u1y = (e.y - o.y) * inv.y, u1z = (e.z - o.z) * inv.z;
+            // fminf/fmaxf are NaN-suppressing like Rust f32::min/max
+            float tmin0 = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
+            float tmax0 = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
+            float tmin1 = fmaxf(fmaxf(fminf(u0x, u1x), fminf(u0y, u1y)), fminf(u0z, u1z));
+            float tmax1 = fminf(fminf(fmaxf(u0x, u1x), fmaxf(u0y, u1y)), fmaxf(u0z, u1z));
+            // the reference's acceptance, plus culling against the closest hit (with slack so that
+            // equal-t candidates are still visited)
+            float limit = hit.t * 1.0000153f;
+            bool h0 = tmax0 >= 0.0f && tmin0 <= tmax0 && tmin0 <= limit;
+            bool h1 = tmax1 >= 0.0f && tmin1 <= tmax1 && tmin1 <= limit;
+            uint32_t c0 = __float_as_uint(a.w), c1 = __float_as_uint(b.w);
+            if (h0 && h1) {
+                bool first0 = tmin0 <= tmin1;
+                if (sp < RT_DEV_STACK_DEPTH) { // cannot trigger: the builder bounds the depth
+                    stack[sp * WAVE] = first0 ? c1 : c0;
+                    sp++;
+                }
+                cur = first0 ? c0 : c1;
+                continue;
+            } else if (h0) {
+                cur = c0;
+                continue;
+            } else if (h1) {
+                cur = c1;
+                continue;
+            }
+        } else {
+            uint32_t start = cur & RT_DEV_LEAF_START_MASK;
+            uint32_t count = (cur >> RT_DEV_LEAF_COUNT_SHIFT) & 0xFu;
+            for (uint32_t i = 0; i < count; i++) {
+                if (COUNT) cnt.tris++;
+                test_triangle(sc.tris, start + i, o, d, hit);
+            }
+        }
+        if (sp == 0) break;
+        sp--;
+        cur = stack[sp * WAVE];
+    }
+}
+
+// find_closest_intersection (shader/src/lib.rs:174-249): spheres first, then triangles with
+// max_t = sphere t; a triangle is only accepted strictly closer, so it wins when both hit.
+template <bool COUNT>
+__device__ __forceinline__ Hit find_closest(const DevScene& sc, V3 o, V3 d, uint32_t* stack, Counts& cnt) {
+    Hit hit;
+    hit.t = RT_F32_MAX; // f32::MAX - 2.0 == f32::MAX
+    hit.prim = RT_PRIM_MISS;
+    hit.slot = 0;
+    test_spheres(sc, o, d, hit);
+    traverse<COUNT>(sc, o, d, stack, hit, cnt);
+    return hit;
+}
+
+// ------------------------------------------------------------------------------------
+// Shading: calculate_shading (shader/src/lib.rs:300-338), LightingCalculator
+// (shader/src/lighting.rs:20-139), MaterialEvaluator (shader/src/material.rs:16-83).
+// Returns the colour of all three channel passes at once: component c is what the
+// channel-c dispatch would have kept (filter_color_by_channel, lib.rs:342-349).
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ V3 evaluate_brdf(const DevMaterial& m, float intensity) {
+    V3 albedo = ld3(m.albedo);
+    V3 diffuse = albedo / RT_PI;
+    float is_metallic = (m.metallic > 0.5f) ? 1.0f : 0.0f;
+    V3 metallic_contrib = albedo * intensity * 0.5f;
+    V3 dielectric_contrib = diffuse * intensity;
+    return metallic_contrib * is_metallic + dielectric_contrib * (1.0f - is_metallic);
+}
+
+__device__ __forceinline__ V3 calculate_lighting(const DevScene& sc, const DevMaterial& m, V3 point, V3 normal) {
+    V3 total = v3(0.0f, 0.0f, 0.0f);
+    total = total + ld3(m.albedo) * 0.1f; // ambient, lighting.rs:30-31
+    for (uint32_t li = 0; li < sc.n_lights; li++) {
+        const DevLight& L = sc.lights[li];
+        V3 ldir = ld3(L.direction);
+        V3 dir_light_dir = -normalize(ldir); // lighting.rs:103
+        float dir_intensity = fmaxf(dot(normal, dir_light_dir), 0.0f) * L.intensity;
+        V3 to_light = ld3(L.position) - point; // lighting.rs:120-122
+        float distance = length(to_light);
+        V3 pld = normalize(to_light);
+        float att = f16_round_trip(1.0f / (1.0f + distance * distance * 0.01f)); // :125-127
+        float point_intensity = fmaxf(dot(normal, pld), 0.0f) * L.intensity * att;
+        float spot_factor = fmaxf(dot(-normalize(ldir), pld), 0.0f); // :132
+        float spot_intensity = point_intensity * spot_factor;
+        float is_dir = (L.light_type == 0) ? 1.0f : 0.0f;
+        float is_point = (L.light_type == 1) ? 1.0f : 0.0f;
+        float is_spot = (L.light_type == 2) ? 1.0f : 0.0f;
+        float final_i = dir_intensity * is_dir + point_intensity * is_point + spot_intensity * is_spot;
+        V3 brdf = evaluate_brdf(m, final_i);
+        float valid = (final_i > 0.0f) ? 1.0f : 0.0f; // index_valid is always 1 inside the loop
+        total = total + brdf * ld3(L.color) * valid;
+    }
+    return total + ld3(m.emission);
+}
+
+__device__ __forceinline__ V3 shade_hit(const DevScene& sc, const Hit& hit, V3 o, V3 d) {
+    V3 point = o + d * hit.t; // Ray::at, ray.rs:56-58
+    V3 normal;
+    uint32_t material_id;
+    if (hit.prim & RT_PRIM_SPHERE_FLAG) {
+        const DevSphere& s = sc.spheres[hit.slot];
+        normal = normalize(point - ld3(s.center)); // intersection.rs:80
+        material_id = s.material_id;
+    } else {
+        const float4* p = reinterpret_cast<const float4*>(sc.tris + hit.slot);
+        float4 q0 = p[0], q1 = p[1], q2 = p[2];
+        V3 e1 = v3(q0.w, q1.x, q1.y);
+        V3 e2 = v3(q1.z, q1.w, q2.x);
+        normal = normalize(cross(e1, e2)); // geometric, winding dependent, never flipped (intersection.rs:132)
+        material_id = __float_as_uint(q2.y);
+    }
+    if (material_id >= sc.n_materials) return v3(1.0f, 0.0f, 1.0f); // magenta, lib.rs:307-309
+    const DevMaterial m = sc.materials[material_id];
+    V3 lighting = calculate_lighting(sc, m, point, normal);
+    float tf = fminf(fmaxf(m.transmission, 0.0f), 1.0f); // lib.rs:323
+    if (tf > 0.0f) {
+        // per channel c: ior_c = ior + {-0.018, 0, +0.035}[c]; disp = (ior_c - 1) / (ior - 1)   (material.rs:42-58, lib.rs:326-334)
+        float disp_r = ((m.ior + -0.018f) - 1.0f) / (m.ior - 1.0f);
+        float disp_g = ((m.ior + 0.0f) - 1.0f) / (m.ior - 1.0f);
+        float disp_b = ((m.ior + 0.035f) - 1.0f) / (m.ior - 1.0f);
+        float keep = 1.0f - tf;
+        return v3(lighting.x * keep + (0.2f * disp_r) * tf, lighting.y * keep + (0.2f * disp_g) * tf,
+                  lighting.z * keep + (0.3f * disp_b) * tf);
+    }
+    return lighting;
+}
+
+// Rgba8Unorm store conversion: clamp, scale, round half up; NaN -> 0.
+__device__ __forceinline__ uint32_t unorm8(float v) {
+    if (!(v > 0.0f)) return 0u;
+    if (v >= 1.0f) return 255u;
+    return (uint32_t)floorf(v * 255.0f + 0.5f);
+}
+
+// Block -> pixel mapping shared by the kernels: one wave per 8x8 block of an owned tile.
+struct PixelCoord {
+    uint32_t x, y;
+    bool valid;
+};
+__device__ __forceinline__ PixelCoord block_pixel(const DevFrame& fr) {
+    const uint32_t lane = threadIdx.x;
+    uint32_t ox, oy, tw, th, blk;
+    const uint32_t bpt_x = (fr.tile_size + 7u) >> 3;
+    if (fr.single_tile) {
+        ox = fr.tile_off_x; oy = fr.tile_off_y; tw = fr.tile_w; th = fr.tile_h;
+        blk = blockIdx.x;
+    } else {
+        const uint32_t bpt = bpt_x * bpt_x;
+        uint32_t k = blockIdx.x / bpt;
+        blk = blockIdx.x - k * bpt;
+        uint32_t tile = fr.tile_first + k * fr.tile_stride;
+        uint32_t ty = tile / fr.tiles_x, tx = tile - ty * fr.tiles_x;
+        ox = tx * fr.tile_size; oy = ty * fr.tile_size;
+        tw = min(fr.tile_size, fr.width - ox); // calculate_tile_dimensions, src/compute.rs:194-209
+        th = min(fr.tile_size, fr.height - oy);
+    }
+    uint32_t by = blk / bpt_x, bx = blk - by * bpt_x;
+    uint32_t idx = bx * 8u + (lane & 7u), idy = by * 8u + (lane >> 3);
+    PixelCoord pc;
+    pc.x = ox + idx;
+    pc.y = oy + idy;
+    // is_pixel_in_bounds, shader/src/lib.rs:152-163
+    pc.valid = idx < tw && idy < th && pc.x < fr.width && pc.y < fr.height;
+    return pc;
+}
+
+// ------------------------------------------------------------------------------------
+// k_render_reference: modes 0 and 1 (reference semantics): one pixel-centre ray per pixel,
+// closest hit, direct lighting; miss = black (mode 0, lib.rs:77) or sky (mode 1,
+// wavefront.rs:146-151).  Mode 1 only produces colour when current_bounce <= max_bounce
+// (lib.rs:117-121), otherwise (0,0,0).
+// ------------------------------------------------------------------------------------
+template <bool COUNT>
+__global__ __launch_bounds__(WAVE) void k_render_reference(DevScene sc, DevFrame fr, DevTargets tg) {
+    __shared__ uint32_t s_stack[RT_DEV_STACK_DEPTH * WAVE];
+    PixelCoord px = block_pixel(fr);
+    if (!px.valid) return;
+    uint32_t* stack = s_stack + threadIdx.x;
+    Counts cnt = {0u, 0u};
+    const bool wavefront = fr.mode != 0;
+    V3 color = v3(0.0f, 0.0f, 0.0f);
+    Hit hit;
+    hit.t = RT_F32_MAX;
+    hit.prim = RT_PRIM_MISS;
+    hit.slot = 0;
+    const bool traced = !wavefront || fr.cur_bounce <= fr.max_bounce;
+    if (traced) {
+        V3 o, d;
+        camera_ray(fr.cam, (float)px.x + 0.5f, (float)px.y + 0.5f, wavefront, o, d);
+        hit = find_closest<COUNT>(sc, o, d, stack, cnt);
+        if (hit.prim != RT_PRIM_MISS) color = shade_hit(sc, hit, o, d);
+        else if (wavefront) color = v3(0.1f, 0.2f, 0.3f);
+    }
+    const size_t pix = (size_t)px.y * fr.width + px.x;
+    if (tg.rgba32f) reinterpret_cast<float4*>(tg.rgba32f)[pix] = make_float4(color.x, color.y, color.z, 1.0f);
+    if (tg.prim_id) tg.prim_id[pix] = hit.prim;
+    if (tg.hit_t) tg.hit_t[pix] = hit.t;
+    // channel texture c keeps only component c (filter_color_by_channel) and alpha 1
+    if ((fr.channel_mask & 1u) && tg.chan[0]) reinterpret_cast<uint32_t*>(tg.chan[0])[pix] = unorm8(color.x) | 0xFF000000u;
+    if ((fr.channel_mask & 2u) && tg.chan[1]) reinterpret_cast<uint32_t*>(tg.chan[1])[pix] = (unorm8(color.y) << 8) | 0xFF000000u;
+    if ((fr.channel_mask & 4u) && tg.chan[2]) reinterpret_cast<uint32_t*>(tg.chan[2])[pix] = (unorm8(color.z) << 16) | 0xFF000000u;
+    if (COUNT && tg.counters) {
+        atomicAdd(&tg.counters[0], traced ? 1ull : 0ull);
+        atomicAdd(&tg.counters[1], (unsigned long long)cnt.nodes);
+        atomicAdd(&tg.counters[2], (unsigned long long)cnt.tris);
+        atomicAdd(&tg.counters[3], traced ? 1ull : 0ull);
+    }
+}
+
+} // namespace
+
+namespace rt {
+
+uint32_t blocks_per_tile(uint32_t tile_size) {
+    uint32_t b = (tile_size + 7u) >> 3;
+    return b * b;
+}
+
+hipError_t launch_render_reference(const DevScene& sc, const DevFrame& fr, const DevTargets& tg, bool counters, hipStream_t stream) {
+    uint32_t n_tiles = fr.single_tile ? 1u : fr.n_owned_tiles;
+    if (n_tiles == 0) return hipSuccess;
+    dim3 grid(n_tiles * blocks_per_tile(fr.tile_size)), block(WAVE);
+    if (counters)
+        hipLaunchKernelGGL(k_render_reference<true>, grid, block, 0, stream, sc, fr, tg);
+    else
+        hipLaunchKernelGGL(k_render_reference<false>, grid, block, 0, stream, sc, fr, tg);
+    return hipGetLastError();
+}
+
+} // namespace rt

@@ -1,0 +1,617 @@
+// rt_api.cpp — the C ABI of include/rt_hip.h: context, scene upload, frame / tile
+// dispatch, read-back.  Replaces the reference's wgpu plumbing
+// (src/buffers.rs:157-470 uploads, src/compute.rs:137-251 dispatch loop,
+// src/renderer.rs:452-475 channel textures).  No CPU fallback: every compute entry point
+// needs a HIP device and fails with RT_ERR_HIP otherwise.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_hip.h"
+#include "bvh_builder.h"
+#include "device_layout.h"
+#include "half.h"
+#include "kernels.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DeviceState {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    DevNode* nodes = nullptr;
+    DevTri* tris = nullptr;
+    DevSphere* spheres = nullptr;
+    DevLight* lights = nullptr;
+    DevMaterial* materials = nullptr;
+    float* rgba32f = nullptr;
+    uint8_t* chan[3] = {nullptr, nullptr, nullptr};
+    uint32_t* prim_id = nullptr;
+    float* hit_t = nullptr;
+    unsigned long long* counters = nullptr;
+    uint32_t fb_w = 0, fb_h = 0;
+    uint32_t tile_first = 0, tile_stride = 1, n_owned = 0; // of the last rt_render
+};
+
+} // namespace
+
+struct rt_ctx {
+    std::vector<DeviceState> devs;
+    std::string err;
+    bool uploaded = false;
+    DevScene scene_counts{}; // counts + root_ref; pointers are per device
+    rt_stats stats{};
+    uint32_t frame_w = 0, frame_h = 0, frame_tile = RT_TILE_SIZE, frame_tiles_x = 0, frame_tiles_y = 0;
+    bool frame_valid = false;
+
+    int fail(int code, const char* fmt, ...) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        err = buf;
+        return code;
+    }
+};
+
+namespace {
+
+#define HIPCHK(ctx, call)                                                                                       \
+    do {                                                                                                        \
+        hipError_t e_ = (call);                                                                                 \
+        if (e_ != hipSuccess)                                                                                   \
+            return (ctx)->fail(e_ == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP, "%s failed: %s (%s:%d)", #call, \
+                               hipGetErrorString(e_), __FILE__, __LINE__);                                     \
+    } while (0)
+
+double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+void free_scene(DeviceState& d) {
+    (void)hipSetDevice(d.device);
+    (void)hipFree(d.nodes); (void)hipFree(d.tris); (void)hipFree(d.spheres); (void)hipFree(d.lights); (void)hipFree(d.materials);
+    d.nodes = nullptr; d.tris = nullptr; d.spheres = nullptr; d.lights = nullptr; d.materials = nullptr;
+}
+void free_targets(DeviceState& d) {
+    (void)hipSetDevice(d.device);
+    (void)hipFree(d.rgba32f); (void)hipFree(d.chan[0]); (void)hipFree(d.chan[1]); (void)hipFree(d.chan[2]); (void)hipFree(d.prim_id); (void)hipFree(d.hit_t);
+    d.rgba32f = nullptr; d.chan[0] = d.chan[1] = d.chan[2] = nullptr; d.prim_id = nullptr; d.hit_t = nullptr;
+    d.fb_w = d.fb_h = 0;
+}
+
+template <class T>
+int upload_array(rt_ctx* ctx, T** dst, const std::vector<T>& src) {
+    *dst = nullptr;
+    if (src.empty()) return RT_OK;
+    HIPCHK(ctx, hipMalloc((void**)dst, src.size() * sizeof(T)));
+    HIPCHK(ctx, hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return RT_OK;
+}
+
+int ensure_targets(rt_ctx* ctx, DeviceState& d, uint32_t w, uint32_t h) {
+    if (d.fb_w == w && d.fb_h == h && d.rgba32f) return RT_OK;
+    free_targets(d);
+    HIPCHK(ctx, hipSetDevice(d.device));
+    size_t n = (size_t)w * h;
+    HIPCHK(ctx, hipMalloc((void**)&d.rgba32f, n * 16));
+    for (int c = 0; c < 3; c++) HIPCHK(ctx, hipMalloc((void**)&d.chan[c], n * 4));
+    HIPCHK(ctx, hipMalloc((void**)&d.prim_id, n * 4));
+    HIPCHK(ctx, hipMalloc((void**)&d.hit_t, n * 4));
+    // fresh textures read as zero, like newly created wgpu textures
+    HIPCHK(ctx, hipMemset(d.rgba32f, 0, n * 16));
+    for (int c = 0; c < 3; c++) HIPCHK(ctx, hipMemset(d.chan[c], 0, n * 4));
+    HIPCHK(ctx, hipMemset(d.prim_id, 0xFF, n * 4));
+    HIPCHK(ctx, hipMemset(d.hit_t, 0, n * 4));
+    d.fb_w = w;
+    d.fb_h = h;
+    return RT_OK;
+}
+
+// Per-frame camera constants in the reference's operation order (shader/src/ray.rs:33-44;
+// wavefront.rs:87-98 for mode 1, which uses the f32 resolution directly).
+DevCamera make_camera(const rt_camera& cam, float res_x, float res_y, bool wavefront) {
+    DevCamera c;
+    float wf, hf;
+    if (wavefront) {
+        wf = res_x;
+        hf = res_y;
+    } else { // `resolution[i] as u32` then `as f32` (ray.rs:23-24, 28-29, 33)
+        auto as_u32 = [](float f) -> uint32_t { return !(f > 0.0f) ? 0u : (f >= 4294967296.0f ? 0xFFFFFFFFu : (uint32_t)f); };
+        wf = (float)as_u32(res_x);
+        hf = (float)as_u32(res_y);
+    }
+    c.width_f = wf;
+    c.height_f = hf;
+    c.aspect = wf / hf;
+    c.fov_scale = tanf(cam.fov * 0.5f * 3.14159265358979323846f / 180.0f);
+    const float* f = cam.direction;
+    const float* u = cam.up;
+    // glam cross: (a.y*b.z - b.y*a.z, a.z*b.x - b.z*a.x, a.x*b.y - b.x*a.y)
+    float r[3] = {f[1] * u[2] - u[1] * f[2], f[2] * u[0] - u[2] * f[0], f[0] * u[1] - u[0] * f[1]};
+    float t[3] = {r[1] * f[2] - f[1] * r[2], r[2] * f[0] - f[2] * r[0], r[0] * f[1] - f[0] * r[1]};
+    for (int a = 0; a < 3; a++) {
+        c.origin[a] = cam.position[a];
+        c.forward[a] = f[a];
+        c.right[a] = r[a];
+        c.true_up[a] = t[a];
+    }
+    return c;
+}
+
+DevScene scene_for(const rt_ctx* ctx, const DeviceState& d) {
+    DevScene s = ctx->scene_counts;
+    s.nodes = d.nodes;
+    s.tris = d.tris;
+    s.spheres = d.spheres;
+    s.lights = d.lights;
+    s.materials = d.materials;
+    return s;
+}
+
+DevTargets targets_for(const DeviceState& d) {
+    DevTargets t;
+    t.rgba32f = d.rgba32f;
+    for (int c = 0; c < 3; c++) t.chan[c] = d.chan[c];
+    t.prim_id = d.prim_id;
+    t.hit_t = d.hit_t;
+    t.counters = d.counters;
+    return t;
+}
+
+int upload_common(rt_ctx* ctx, const rt_sphere* spheres, uint32_t n_spheres, const rt_light* lights, uint32_t n_lights,
+                  const rt_vertex* vertices, uint32_t n_vertices, const std::vector<rt_triangle>& tris,
+                  const std::vector<uint32_t>& prim_ids, const rt_material* materials, uint32_t n_materials) {
+    if (tris.size() > RT_DEV_MAX_TRIS) return ctx->fail(RT_ERR_BAD_ARG, "too many triangles: %zu > %u", tris.size(), RT_DEV_MAX_TRIS);
+    std::vector<rt::BuildTri> bt(tris.size());
+    for (size_t i = 0; i < tris.size(); i++) {
+        const rt_triangle& t = tris[i];
+        if (t.v0_index >= n_vertices || t.v1_index >= n_vertices || t.v2_index >= n_vertices)
+            return ctx->fail(RT_ERR_BAD_ARG, "triangle %zu references vertex out of range (%u,%u,%u >= %u)", i, t.v0_index,
+                             t.v1_index, t.v2_index, n_vertices);
+        std::memcpy(bt[i].v0, vertices[t.v0_index].position, 12);
+        std::memcpy(bt[i].v1, vertices[t.v1_index].position, 12);
+        std::memcpy(bt[i].v2, vertices[t.v2_index].position, 12);
+        bt[i].material_id = t.material_id;
+        bt[i].prim_id = prim_ids.empty() ? (uint32_t)i : prim_ids[i];
+    }
+    rt::BvhBuild bvh;
+    rt::BvhBuildOptions opt;
+    double t0 = now_ms();
+    rt::build_bvh(bt.data(), bt.size(), opt, bvh);
+    double build_ms = now_ms() - t0;
+    (void)build_ms;
+    if (bvh.depth > RT_DEV_STACK_DEPTH) return ctx->fail(RT_ERR_INTERNAL, "BVH depth %u exceeds the traversal stack %d", bvh.depth, RT_DEV_STACK_DEPTH);
+
+    std::vector<DevSphere> ds(n_spheres);
+    for (uint32_t i = 0; i < n_spheres; i++) {
+        std::memcpy(ds[i].center, spheres[i].center, 12);
+        ds[i].radius = spheres[i].radius;
+        ds[i].material_id = spheres[i].material_id;
+        ds[i]._pad[0] = ds[i]._pad[1] = ds[i]._pad[2] = 0;
+    }
+    std::vector<DevLight> dl(n_lights);
+    for (uint32_t i = 0; i < n_lights; i++) {
+        std::memcpy(dl[i].position, lights[i].position, 12);
+        dl[i].light_type = lights[i].light_type;
+        std::memcpy(dl[i].color, lights[i].color, 12);
+        dl[i].intensity = lights[i].intensity;
+        std::memcpy(dl[i].direction, lights[i].direction, 12);
+        dl[i]._pad = 0;
+    }
+    std::vector<DevMaterial> dm(n_materials);
+    for (uint32_t i = 0; i < n_materials; i++) { // MaterialEvaluator accessors, shader/src/material.rs:16-63
+        const rt_material& m = materials[i];
+        std::memcpy(dm[i].albedo, m.albedo, 12);
+        std::memcpy(dm[i].emission, m.emission, 12);
+        dm[i].metallic = rt::f16_bits_to_f32((uint16_t)(m.metallic_roughness_f16 & 0xFFFF));
+        dm[i].roughness = rt::f16_bits_to_f32((uint16_t)(m.metallic_roughness_f16 >> 16));
+        dm[i].ior = rt::f16_bits_to_f32((uint16_t)(m.ior_transmission_f16 & 0xFFFF));
+        dm[i].transmission = rt::f16_bits_to_f32((uint16_t)(m.ior_transmission_f16 >> 16));
+        dm[i]._pad[0] = dm[i]._pad[1] = 0.0f;
+    }
+
+    for (auto& d : ctx->devs) {
+        free_scene(d);
+        HIPCHK(ctx, hipSetDevice(d.device));
+        int rc;
+        if ((rc = upload_array(ctx, &d.nodes, bvh.nodes)) != RT_OK) return rc;
+        if ((rc = upload_array(ctx, &d.tris, bvh.tris)) != RT_OK) return rc;
+        if ((rc = upload_array(ctx, &d.spheres, ds)) != RT_OK) return rc;
+        if ((rc = upload_array(ctx, &d.lights, dl)) != RT_OK) return rc;
+        if ((rc = upload_array(ctx, &d.materials, dm)) != RT_OK) return rc;
+    }
+    DevScene& sc = ctx->scene_counts;
+    sc = DevScene{};
+    sc.n_nodes = (uint32_t)bvh.nodes.size();
+    sc.n_tris = (uint32_t)bvh.tris.size();
+    sc.n_spheres = n_spheres;
+    sc.n_lights = n_lights;
+    sc.n_materials = n_materials;
+    sc.root_ref = bvh.root_ref;
+    ctx->stats = rt_stats{};
+    ctx->stats.node_bytes = sizeof(DevNode);
+    ctx->stats.tri_bytes = sizeof(DevTri);
+    ctx->stats.scene_bytes = bvh.nodes.size() * sizeof(DevNode) + bvh.tris.size() * sizeof(DevTri) + ds.size() * sizeof(DevSphere) +
+                             dl.size() * sizeof(DevLight) + dm.size() * sizeof(DevMaterial);
+    ctx->stats.bvh_nodes = sc.n_nodes;
+    ctx->stats.bvh_depth = bvh.depth;
+    ctx->stats.n_devices = (uint32_t)ctx->devs.size();
+    ctx->uploaded = true;
+    ctx->frame_valid = false;
+    return RT_OK;
+}
+
+// Launch one frame (or one explicit tile) on every device and wait.
+int run_frame(rt_ctx* ctx, DevFrame fr, bool counters, uint32_t world, uint32_t rank, bool single_tile) {
+    double w0 = now_ms();
+    size_t nd = single_tile ? 1 : ctx->devs.size();
+    uint32_t total_tiles = fr.tiles_x * fr.tiles_y;
+    for (size_t j = 0; j < nd; j++) {
+        DeviceState& d = ctx->devs[j];
+        HIPCHK(ctx, hipSetDevice(d.device));
+        int rc = ensure_targets(ctx, d, fr.width, fr.height);
+        if (rc != RT_OK) return rc;
+        DevFrame f = fr;
+        if (!single_tile) {
+            uint32_t stride = world * (uint32_t)nd, first = rank * (uint32_t)nd + (uint32_t)j;
+            f.tile_first = first;
+            f.tile_stride = stride;
+            f.n_owned_tiles = first < total_tiles ? (total_tiles - first + stride - 1) / stride : 0;
+            d.tile_first = first;
+            d.tile_stride = stride;
+            d.n_owned = f.n_owned_tiles;
+        }
+        HIPCHK(ctx, hipMemsetAsync(d.counters, 0, 4 * sizeof(unsigned long long), d.stream));
+        HIPCHK(ctx, hipEventRecord(d.ev0, d.stream));
+        HIPCHK(ctx, rt::launch_render_reference(scene_for(ctx, d), f, targets_for(d), counters, d.stream));
+        HIPCHK(ctx, hipEventRecord(d.ev1, d.stream));
+    }
+    double kernel_ms = 0.0;
+    unsigned long long cnt[4] = {0, 0, 0, 0};
+    uint64_t pixels = 0;
+    for (size_t j = 0; j < nd; j++) {
+        DeviceState& d = ctx->devs[j];
+        HIPCHK(ctx, hipSetDevice(d.device));
+        HIPCHK(ctx, hipStreamSynchronize(d.stream));
+        float ms = 0.0f;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, d.ev0, d.ev1));
+        kernel_ms = std::max(kernel_ms, (double)ms);
+        if (counters) {
+            unsigned long long c[4];
+            HIPCHK(ctx, hipMemcpy(c, d.counters, sizeof c, hipMemcpyDeviceToHost));
+            for (int k = 0; k < 4; k++) cnt[k] += c[k];
+        }
+        if (single_tile) {
+            pixels += (uint64_t)std::min(fr.tile_w, fr.width - std::min(fr.width, fr.tile_off_x)) *
+                      std::min(fr.tile_h, fr.height - std::min(fr.height, fr.tile_off_y));
+        } else {
+            for (uint32_t k = 0; k < d.n_owned; k++) {
+                uint32_t tile = d.tile_first + k * d.tile_stride;
+                uint32_t ty = tile / fr.tiles_x, tx = tile % fr.tiles_x;
+                pixels += (uint64_t)std::min(fr.tile_size, fr.width - tx * fr.tile_size) * std::min(fr.tile_size, fr.height - ty * fr.tile_size);
+            }
+        }
+    }
+    rt_stats& st = ctx->stats;
+    st.pixels = pixels;
+    bool traced = fr.mode == RT_MODE_LEGACY || fr.cur_bounce <= fr.max_bounce;
+    st.rays = traced ? pixels : 0; // modes 0/1: one segment per pixel
+    st.primary_rays = st.rays;
+    st.node_visits = counters ? cnt[1] : 0;
+    st.tri_tests = counters ? cnt[2] : 0;
+    st.kernel_ms = kernel_ms;
+    st.wall_ms = now_ms() - w0;
+    return RT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* rt_version(void) { return "librt_hip 0.1 gfx950 (fp-contract=off, IEEE div/sqrt)"; }
+
+const char* rt_last_error(rt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int rt_create(rt_ctx** out, const int* device_ids, int n_devices) {
+    if (!out || n_devices < 1) {
+        g_create_error = "rt_create: bad arguments";
+        return RT_ERR_BAD_ARG;
+    }
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count < 1) {
+        g_create_error = std::string("rt_create: no HIP device (") + hipGetErrorString(e) + "); this library has no CPU fallback";
+        return RT_ERR_HIP;
+    }
+    rt_ctx* ctx = new rt_ctx();
+    for (int i = 0; i < n_devices; i++) {
+        DeviceState d;
+        d.device = device_ids ? device_ids[i] : i;
+        if (d.device < 0 || d.device >= count) {
+            g_create_error = "rt_create: device id out of range";
+            rt_destroy(ctx);
+            return RT_ERR_BAD_ARG;
+        }
+        if ((e = hipSetDevice(d.device)) != hipSuccess || (e = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking)) != hipSuccess ||
+            (e = hipEventCreate(&d.ev0)) != hipSuccess || (e = hipEventCreate(&d.ev1)) != hipSuccess ||
+            (e = hipMalloc((void**)&d.counters, 4 * sizeof(unsigned long long))) != hipSuccess) {
+            g_create_error = std::string("rt_create: ") + hipGetErrorString(e);
+            ctx->devs.push_back(d);
+            rt_destroy(ctx);
+            return RT_ERR_HIP;
+        }
+        ctx->devs.push_back(d);
+    }
+    *out = ctx;
+    return RT_OK;
+}
+
+void rt_destroy(rt_ctx* ctx) {
+    if (!ctx) return;
+    for (auto& d : ctx->devs) {
+        if (d.device < 0) continue;
+        (void)hipSetDevice(d.device);
+        if (d.stream) (void)hipStreamSynchronize(d.stream);
+        free_scene(d);
+        free_targets(d);
+        (void)hipFree(d.counters);
+        if (d.ev0) (void)hipEventDestroy(d.ev0);
+        if (d.ev1) (void)hipEventDestroy(d.ev1);
+        if (d.stream) (void)hipStreamDestroy(d.stream);
+    }
+    delete ctx;
+}
+
+int rt_upload_scene(rt_ctx* ctx, const rt_sphere* spheres, uint32_t n_spheres, const rt_light* lights, uint32_t n_lights,
+                    const rt_vertex* vertices, uint32_t n_vertices, const rt_triangle* triangles, uint32_t n_triangles,
+                    const rt_material* materials, uint32_t n_materials, const rt_bvh_node* ref_nodes, uint32_t n_ref_nodes,
+                    const uint32_t* ref_tri_indices, uint32_t n_ref_tri_indices) {
+    if (!ctx) return RT_ERR_BAD_ARG;
+    if ((n_spheres && !spheres) || (n_lights && !lights) || (n_vertices && !vertices) || (n_triangles && !triangles) ||
+        (n_materials && !materials))
+        return ctx->fail(RT_ERR_BAD_ARG, "rt_upload_scene: null array with non-zero count");
+    // The reference BVH is accepted for interface compatibility and sanity-checked only.
+    if (ref_nodes) {
+        for (uint32_t i = 0; i < n_ref_nodes; i++) {
+            const rt_bvh_node& n = ref_nodes[i];
+            bool leaf = n.left_child == RT_INVALID_INDEX;
+            if (!leaf && (n.left_child >= n_ref_nodes || (n.right_child != RT_INVALID_INDEX && n.right_child >= n_ref_nodes)))
+                return ctx->fail(RT_ERR_BAD_ARG, "reference BVH node %u has a child out of range", i);
+            if (leaf && ref_tri_indices && (uint64_t)n.triangle_start + n.triangle_count > n_ref_tri_indices)
+                return ctx->fail(RT_ERR_BAD_ARG, "reference BVH leaf %u exceeds triangle_indices", i);
+        }
+    }
+    std::vector<rt_triangle> tris(triangles, triangles + n_triangles);
+    return upload_common(ctx, spheres, n_spheres, lights, n_lights, vertices, n_vertices, tris, {}, materials, n_materials);
+}
+
+int rt_upload_scene_packed(rt_ctx* ctx, const uint32_t* md, size_t n_u32, const rt_scene_metadata_offsets* off,
+                           const rt_triangle* const tri_buffers[3], const uint32_t tri_counts[3], uint32_t triangles_per_buffer,
+                           const rt_material* materials, uint32_t n_materials) {
+    if (!ctx) return RT_ERR_BAD_ARG;
+    if (!off || (n_u32 && !md) || !tri_buffers || !tri_counts || (n_materials && !materials))
+        return ctx->fail(RT_ERR_BAD_ARG, "rt_upload_scene_packed: null argument");
+    auto section_ok = [&](uint32_t o, uint32_t count, uint32_t words) { return (uint64_t)o + (uint64_t)count * words <= n_u32; };
+    if (!section_ok(off->spheres_offset, off->spheres_count, RT_SPHERE_WORDS) ||
+        !section_ok(off->lights_offset, off->lights_count, RT_LIGHT_WORDS) ||
+        !section_ok(off->bvh_nodes_offset, off->bvh_nodes_count, RT_BVH_NODE_WORDS) ||
+        !section_ok(off->triangle_indices_offset, off->triangle_indices_count, 1) ||
+        !section_ok(off->vertices_offset, off->vertices_count, RT_VERTEX_WORDS))
+        return ctx->fail(RT_ERR_BAD_ARG, "rt_upload_scene_packed: a metadata section exceeds the buffer (%zu words)", n_u32);
+    // Sections are plain reinterpretations of the host Vec<T> bytes (src/buffers.rs:213-234).
+    const rt_sphere* spheres = reinterpret_cast<const rt_sphere*>(md + off->spheres_offset);
+    const rt_light* lights = reinterpret_cast<const rt_light*>(md + off->lights_offset);
+    const rt_vertex* vertices = reinterpret_cast<const rt_vertex*>(md + off->vertices_offset);
+    std::vector<rt_triangle> tris;
+    std::vector<uint32_t> prim_ids;
+    for (int b = 0; b < 3; b++) {
+        if (tri_counts[b] == 0) continue;
+        if (!tri_buffers[b]) return ctx->fail(RT_ERR_BAD_ARG, "rt_upload_scene_packed: triangle buffer %d is null", b);
+        if (triangles_per_buffer == 0 || tri_counts[b] > triangles_per_buffer)
+            return ctx->fail(RT_ERR_BAD_ARG, "rt_upload_scene_packed: buffer %d holds %u > triangles_per_buffer %u", b, tri_counts[b],
+                             triangles_per_buffer);
+        for (uint32_t i = 0; i < tri_counts[b]; i++) {
+            tris.push_back(tri_buffers[b][i]);
+            prim_ids.push_back((uint32_t)b * triangles_per_buffer + i); // logical index, shader/src/triangle_access.rs:26-27
+        }
+    }
+    return upload_common(ctx, spheres, off->spheres_count, lights, off->lights_count, vertices, off->vertices_count, tris, prim_ids,
+                         materials, n_materials);
+}
+
+int rt_render(rt_ctx* ctx, const rt_render_params* p) {
+    if (!ctx) return RT_ERR_BAD_ARG;
+    if (!p) return ctx->fail(RT_ERR_BAD_ARG, "rt_render: null params");
+    if (!ctx->uploaded) return ctx->fail(RT_ERR_NOT_UPLOADED, "rt_render: no scene uploaded");
+    if (p->width == 0 || p->height == 0 || p->width > 65535u * 8u || p->height > 65535u * 8u)
+        return ctx->fail(RT_ERR_BAD_ARG, "rt_render: bad resolution %ux%u", p->width, p->height);
+    if (p->mode != RT_MODE_LEGACY && p->mode != RT_MODE_WAVEFRONT)
+        return ctx->fail(RT_ERR_BAD_ARG, "rt_render: mode %u not supported", p->mode);
+    uint32_t world = p->tile_world ? p->tile_world : 1, rank = p->tile_rank;
+    if (rank >= world) return ctx->fail(RT_ERR_BAD_ARG, "rt_render: tile_rank %u >= tile_world %u", rank, world);
+    DevFrame fr{};
+    fr.width = p->width;
+    fr.height = p->height;
+    fr.tile_size = p->tile_size ? p->tile_size : RT_TILE_SIZE;
+    if (fr.tile_size > 4096) return ctx->fail(RT_ERR_BAD_ARG, "rt_render: tile_size %u too large", fr.tile_size);
+    fr.tiles_x = (fr.width + fr.tile_size - 1) / fr.tile_size; // TileHelper::calculate_tile_count, shared/src/lib.rs:1187-1191
+    fr.tiles_y = (fr.height + fr.tile_size - 1) / fr.tile_size;
+    fr.mode = p->mode;
+    fr.channel_mask = 7u;
+    fr.cur_bounce = 0; // the bounce-0 pass of src/compute.rs:413-479 (later passes redraw the same pixels)
+    fr.max_bounce = p->max_bounces & 0xFF;
+    fr.spp = 1;
+    fr.frame_seed = p->frame_seed;
+    fr.cam = make_camera(p->camera, (float)p->width, (float)p->height, p->mode != RT_MODE_LEGACY);
+    int rc = run_frame(ctx, fr, (p->flags & RT_FLAG_COUNTERS) != 0, world, rank, false);
+    if (rc != RT_OK) return rc;
+    ctx->frame_w = fr.width;
+    ctx->frame_h = fr.height;
+    ctx->frame_tile = fr.tile_size;
+    ctx->frame_tiles_x = fr.tiles_x;
+    ctx->frame_tiles_y = fr.tiles_y;
+    ctx->frame_valid = true;
+    return RT_OK;
+}
+
+int rt_dispatch_tile(rt_ctx* ctx, const rt_push_constants* pc) {
+    if (!ctx) return RT_ERR_BAD_ARG;
+    if (!pc) return ctx->fail(RT_ERR_BAD_ARG, "rt_dispatch_tile: null push constants");
+    if (!ctx->uploaded) return ctx->fail(RT_ERR_NOT_UPLOADED, "rt_dispatch_tile: no scene uploaded");
+    uint32_t channel = pc->packed_flags & 0xFF;
+    if (channel > 2) return ctx->fail(RT_ERR_BAD_ARG, "rt_dispatch_tile: invalid color channel %u", channel); // src/renderer.rs:769-776
+    auto as_u32 = [](float f) -> uint32_t { return !(f > 0.0f) ? 0u : (f >= 4294967296.0f ? 0xFFFFFFFFu : (uint32_t)f); };
+    uint32_t w = as_u32(pc->resolution[0]), h = as_u32(pc->resolution[1]);
+    if (w == 0 || h == 0 || w > 65535u * 8u || h > 65535u * 8u)
+        return ctx->fail(RT_ERR_BAD_ARG, "rt_dispatch_tile: bad resolution %gx%g", pc->resolution[0], pc->resolution[1]);
+    uint32_t mode = (pc->packed_flags >> 24) & 0xFF;
+    DevFrame fr{};
+    fr.width = w;
+    fr.height = h;
+    fr.single_tile = 1;
+    fr.tile_off_x = pc->tile_offset[0];
+    fr.tile_off_y = pc->tile_offset[1];
+    fr.tile_w = pc->tile_size_packed & 0xFFFF; // unpack_tile_size, shared/src/lib.rs:1146-1150
+    fr.tile_h = (pc->tile_size_packed >> 16) & 0xFFFF;
+    fr.tile_size = std::max(1u, std::max(fr.tile_w, fr.tile_h));
+    fr.tiles_x = fr.tiles_y = 1;
+    fr.mode = mode ? RT_MODE_WAVEFRONT : RT_MODE_LEGACY;
+    fr.channel_mask = 1u << channel;
+    fr.cur_bounce = (pc->packed_flags >> 8) & 0xFF;
+    fr.max_bounce = (pc->packed_flags >> 16) & 0xFF;
+    fr.spp = 1;
+    fr.frame_seed = pc->frame_seed;
+    fr.cam = make_camera(pc->camera, pc->resolution[0], pc->resolution[1], mode != 0);
+    // Only texture `channel` receives texels (the other two keep theirs, as separate bind groups do);
+    // the float and hit targets of the tile are refreshed as a by-product.
+    DeviceState& d = ctx->devs[0];
+    int rc = run_frame(ctx, fr, false, 1, 0, true);
+    if (rc != RT_OK) return rc;
+    ctx->frame_w = w;
+    ctx->frame_h = h;
+    ctx->frame_tile = RT_TILE_SIZE;
+    ctx->frame_tiles_x = (w + RT_TILE_SIZE - 1) / RT_TILE_SIZE;
+    ctx->frame_tiles_y = (h + RT_TILE_SIZE - 1) / RT_TILE_SIZE;
+    ctx->frame_valid = true;
+    // a dispatch sequence is owned entirely by device 0
+    d.tile_first = 0;
+    d.tile_stride = 1;
+    d.n_owned = ctx->frame_tiles_x * ctx->frame_tiles_y;
+    return RT_OK;
+}
+
+// Copy `elem` bytes per pixel of every device's owned tiles into `out` (full frame, row-major).
+static int gather(rt_ctx* ctx, uint8_t* out, size_t elem, int which /*0 rgba32f, 1..3 chan, 4 prim, 5 t*/) {
+    uint32_t w = ctx->frame_w, h = ctx->frame_h;
+    size_t n = (size_t)w * h;
+    std::vector<uint8_t> tmp;
+    for (size_t j = 0; j < ctx->devs.size(); j++) {
+        DeviceState& d = ctx->devs[j];
+        if (d.fb_w != w || d.fb_h != h) continue;
+        const void* src = which == 0 ? (const void*)d.rgba32f : which <= 3 ? (const void*)d.chan[which - 1] : which == 4 ? (const void*)d.prim_id : (const void*)d.hit_t;
+        HIPCHK(ctx, hipSetDevice(d.device));
+        bool all = d.tile_stride == 1 && d.tile_first == 0;
+        if (all) {
+            HIPCHK(ctx, hipMemcpy(out, src, n * elem, hipMemcpyDeviceToHost));
+            continue;
+        }
+        tmp.resize(n * elem);
+        HIPCHK(ctx, hipMemcpy(tmp.data(), src, n * elem, hipMemcpyDeviceToHost));
+        uint32_t ts = ctx->frame_tile;
+        for (uint32_t k = 0; k < d.n_owned; k++) {
+            uint32_t tile = d.tile_first + k * d.tile_stride;
+            uint32_t ty = tile / ctx->frame_tiles_x, tx = tile % ctx->frame_tiles_x;
+            uint32_t x0 = tx * ts, y0 = ty * ts, tw = std::min(ts, w - x0), th = std::min(ts, h - y0);
+            for (uint32_t y = y0; y < y0 + th; y++)
+                std::memcpy(out + ((size_t)y * w + x0) * elem, tmp.data() + ((size_t)y * w + x0) * elem, (size_t)tw * elem);
+        }
+    }
+    return RT_OK;
+}
+
+int rt_read_rgb32f(rt_ctx* ctx, float* out, size_t n_floats) {
+    if (!ctx) return RT_ERR_BAD_ARG;
+    if (!ctx->frame_valid) return ctx->fail(RT_ERR_NOT_UPLOADED, "rt_read_rgb32f: nothing rendered yet");
+    size_t n = (size_t)ctx->frame_w * ctx->frame_h;
+    if (!out || n_floats != n * 3) return ctx->fail(RT_ERR_BAD_ARG, "rt_read_rgb32f: expected %zu floats, got %zu", n * 3, n_floats);
+    std::vector<float> tmp(n * 4, 0.0f);
+    int rc = gather(ctx, reinterpret_cast<uint8_t*>(tmp.data()), 16, 0);
+    if (rc != RT_OK) return rc;
+    for (size_t i = 0; i < n; i++) {
+        out[3 * i + 0] = tmp[4 * i + 0];
+        out[3 * i + 1] = tmp[4 * i + 1];
+        out[3 * i + 2] = tmp[4 * i + 2];
+    }
+    return RT_OK;
+}
+
+int rt_read_rgba8_channels(rt_ctx* ctx, uint8_t* red, uint8_t* green, uint8_t* blue, size_t n_bytes_each) {
+    if (!ctx) return RT_ERR_BAD_ARG;
+    if (!ctx->frame_valid) return ctx->fail(RT_ERR_NOT_UPLOADED, "rt_read_rgba8_channels: nothing rendered yet");
+    size_t n = (size_t)ctx->frame_w * ctx->frame_h * 4;
+    if (n_bytes_each != n) return ctx->fail(RT_ERR_BAD_ARG, "rt_read_rgba8_channels: expected %zu bytes each, got %zu", n, n_bytes_each);
+    uint8_t* outs[3] = {red, green, blue};
+    for (int c = 0; c < 3; c++) {
+        if (!outs[c]) continue;
+        std::memset(outs[c], 0, n);
+        int rc = gather(ctx, outs[c], 4, 1 + c);
+        if (rc != RT_OK) return rc;
+    }
+    return RT_OK;
+}
+
+int rt_read_rgba8_combined(rt_ctx* ctx, uint8_t* out, size_t n_bytes) {
+    if (!ctx) return RT_ERR_BAD_ARG;
+    if (!ctx->frame_valid) return ctx->fail(RT_ERR_NOT_UPLOADED, "rt_read_rgba8_combined: nothing rendered yet");
+    size_t n = (size_t)ctx->frame_w * ctx->frame_h * 4;
+    if (!out || n_bytes != n) return ctx->fail(RT_ERR_BAD_ARG, "rt_read_rgba8_combined: expected %zu bytes, got %zu", n, n_bytes);
+    std::vector<uint8_t> r(n), g(n), b(n);
+    int rc = rt_read_rgba8_channels(ctx, r.data(), g.data(), b.data(), n);
+    if (rc != RT_OK) return rc;
+    for (size_t i = 0; i < n; i += 4) { // main_fs, shader/src/lib.rs:383-388
+        out[i + 0] = r[i + 0];
+        out[i + 1] = g[i + 1];
+        out[i + 2] = b[i + 2];
+        out[i + 3] = 255;
+    }
+    return RT_OK;
+}
+
+int rt_read_hits(rt_ctx* ctx, uint32_t* prim_ids, float* t, size_t n_pixels) {
+    if (!ctx) return RT_ERR_BAD_ARG;
+    if (!ctx->frame_valid) return ctx->fail(RT_ERR_NOT_UPLOADED, "rt_read_hits: nothing rendered yet");
+    size_t n = (size_t)ctx->frame_w * ctx->frame_h;
+    if (n_pixels != n) return ctx->fail(RT_ERR_BAD_ARG, "rt_read_hits: expected %zu pixels, got %zu", n, n_pixels);
+    int rc;
+    if (prim_ids) {
+        std::memset(prim_ids, 0xFF, n * 4);
+        if ((rc = gather(ctx, reinterpret_cast<uint8_t*>(prim_ids), 4, 4)) != RT_OK) return rc;
+    }
+    if (t) {
+        std::memset(t, 0, n * 4);
+        if ((rc = gather(ctx, reinterpret_cast<uint8_t*>(t), 4, 5)) != RT_OK) return rc;
+    }
+    return RT_OK;
+}
+
+int rt_get_stats(rt_ctx* ctx, rt_stats* out) {
+    if (!ctx) return RT_ERR_BAD_ARG;
+    if (!out) return ctx->fail(RT_ERR_BAD_ARG, "rt_get_stats: null out");
+    *out = ctx->stats;
+    return RT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,70 @@
+"""C-ABI boundary checks that need no GPU: the library loads, exports every symbol the header
+declares, and the product path fails loudly (no CPU fallback) when it cannot run."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(rt_api):
+    declared = _declared_symbols("rt_hip.h")
+    assert set(declared) >= set(rt_api.ABI_SYMBOLS)
+    lib = rt_api.load()
+    for name in declared:
+        assert hasattr(lib, name), f"librt_hip.so does not export {name}"
+    assert "gfx950" in rt_api.version()
+
+
+def test_library_is_in_tree_and_has_gfx950_code_object(rt_api):
+    assert os.path.dirname(rt_api.LIB_PATH) == os.path.join(ROOT, "gpu_raytracer_amd")
+    blob = open(rt_api.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob and b"k_render_reference" in blob
+
+
+def test_product_does_not_import_or_link_the_oracle(rt_api):
+    pkg = os.path.join(ROOT, "gpu_raytracer_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")):
+                src = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "import oracle" not in src and "from oracle" not in src and "rt_oracle" not in src and "liboracle" not in src, f
+    assert b"liboracle" not in open(rt_api.LIB_PATH, "rb").read()
+
+
+def test_missing_extension_fails_loudly(monkeypatch):
+    from gpu_raytracer_amd import api
+    monkeypatch.setattr(api, "_lib", None)
+    monkeypatch.setattr(api, "LIB_PATH", "/nonexistent/librt_hip.so")
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        api.load()
+
+
+def test_no_device_is_an_error_not_a_fallback(rt_api):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(rt_api.RtError) as e:
+        rt_api.Context()
+    assert e.value.code == -3 and "no CPU fallback" in str(e.value)
+
+
+def test_null_context_calls_return_bad_arg(rt_api):
+    lib = rt_api.load()
+    null = C.c_void_p(0)
+    assert lib.rt_render(null, null) == -1
+    assert lib.rt_dispatch_tile(null, null) == -1
+    assert lib.rt_get_stats(null, null) == -1
+    assert lib.rt_read_rgb32f(null, null, C.c_size_t(0)) == -1
+    h = C.c_void_p(0)
+    assert lib.rt_create(C.byref(h), null, C.c_int(0)) == -1
+    lib.rt_destroy(null)  # no-op

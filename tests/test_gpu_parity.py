@@ -1,0 +1,244 @@
+"""GPU parity tests (run on the MI355X with -m gpu): the HIP path, called through the C ABI,
+against the CPU oracle on identical seeded inputs.
+
+Bar: float RGB |d| <= 2e-3 and unorm8 |d| <= 1 for >= 99.9 % of pixels.  What the
+kernels actually deliver is stronger and asserted here: closest-primitive indices, hit distances
+and float RGB are BIT-EXACT against the oracle's brute-force path (same Möller–Trumbore
+arithmetic, ties to the lower triangle index), and differ from the oracle's BVH path only at
+equal-t ties, whose order depends on the reference BVH's topology (unpinned).
+"""
+import numpy as np
+import pytest
+
+from gpu_raytracer_amd import hostpack as H
+from gpu_raytracer_amd import scenes
+from gpu_raytracer_amd import types as T
+
+pytestmark = pytest.mark.gpu
+
+FLOAT_TOL = 2e-3  # per channel, BASELINE.md parity gate
+OUTLIER_FRAC = 1e-3
+
+
+def _render_gpu(ctx, scene, w, h, mode=0, **kw):
+    ctx.upload_scene(scene)
+    st = ctx.render(w, h, kw.pop("camera", scene.camera), mode=mode, **kw)
+    prim, t = ctx.read_hits()
+    return {"rgb": ctx.read_rgb32f(), "combined": ctx.read_rgba8_combined(), "chans": ctx.read_rgba8_channels(),
+            "prim": prim, "t": t, "stats": st}
+
+
+def _assert_within_gate(gpu, ref):
+    d = np.abs(gpu["rgb"] - ref["rgb"]).max(-1)
+    assert (d > FLOAT_TOL).mean() <= OUTLIER_FRAC, f"float outliers {(d > FLOAT_TOL).mean():.2e}"
+    d8 = np.abs(gpu["combined"].astype(int) - ref["combined"].astype(int)).max(-1)
+    assert (d8 > 1).mean() <= OUTLIER_FRAC, f"unorm8 outliers {(d8 > 1).mean():.2e}"
+
+
+def _assert_bit_exact(gpu, ref):
+    np.testing.assert_array_equal(gpu["prim"], ref["prim"])
+    np.testing.assert_array_equal(gpu["t"].view(np.uint32), ref["t"].view(np.uint32))
+    np.testing.assert_array_equal(gpu["rgb"].view(np.uint32), ref["rgb"].view(np.uint32))
+    np.testing.assert_array_equal(gpu["combined"], ref["combined"])
+    for c, k in enumerate(("red", "green", "blue")):
+        np.testing.assert_array_equal(gpu["chans"][c], ref[k])
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("name,w,h", [("default", 256, 256), ("empty", 40, 24), ("single_triangle", 130, 70), ("cornell12", 256, 256)])
+def test_small_scenes_bit_exact_vs_brute_force_oracle(gpu_ctx, oracle_mod, name, w, h, mode):
+    scene = scenes.SCENES[name]()
+    ref = oracle_mod.render_frame(oracle_mod.PackedScene(scene, use_bvh=False), w, h, mode=mode)
+    gpu = _render_gpu(gpu_ctx, scene, w, h, mode=mode)
+    _assert_bit_exact(gpu, ref)
+    assert gpu["stats"]["rays"] == w * h
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("name,w,h", [("default", 256, 256), ("cornell12", 256, 256)])
+def test_small_scenes_vs_reference_bvh_path(gpu_ctx, oracle_mod, name, w, h, mode):
+    """Against the oracle walking a reference-format BVH: identical except equal-t ties on shared edges."""
+    scene = scenes.SCENES[name]()
+    ref = oracle_mod.render_frame(oracle_mod.PackedScene(scene, use_bvh=True), w, h, mode=mode)
+    gpu = _render_gpu(gpu_ctx, scene, w, h, mode=mode)
+    np.testing.assert_array_equal(gpu["t"].view(np.uint32), ref["t"].view(np.uint32))
+    assert (gpu["prim"] != ref["prim"]).mean() < 2e-3
+    same = gpu["prim"] == ref["prim"]
+    np.testing.assert_array_equal(gpu["rgb"][same].view(np.uint32), ref["rgb"][same].view(np.uint32))
+
+
+@pytest.mark.parametrize("n,seed,size,spheres", [(1, 1, 1.0, 0), (7, 2, 0.8, 1), (300, 3, 0.5, 3), (5000, 4, 0.3, 2), (60000, 5, 0.12, 0)])
+def test_random_soups_vs_oracle(gpu_ctx, oracle_mod, n, seed, size, spheres):
+    scene = scenes.random_soup(n, seed=seed, size=size, n_spheres=spheres, n_lights=3)
+    w, h = 192, 128
+    use_bvh = n > 400
+    ref = oracle_mod.render_frame(oracle_mod.PackedScene(scene, use_bvh=use_bvh), w, h)
+    gpu = _render_gpu(gpu_ctx, scene, w, h)
+    if not use_bvh:
+        _assert_bit_exact(gpu, ref)
+    else:
+        np.testing.assert_array_equal(gpu["t"].view(np.uint32), ref["t"].view(np.uint32))
+        assert (gpu["prim"] != ref["prim"]).mean() <= OUTLIER_FRAC
+        _assert_within_gate(gpu, ref)
+
+
+def test_sponza_like_vs_faithful_oracle(gpu_ctx, oracle_mod):
+    """262,144 triangles: the oracle walks the reference's chunked BVH (32-triangle mesh-order leaves,
+    no t-culling, src/bvh.rs:154-247), whose first-found tie-break is the lowest triangle index: exact."""
+    scene = scenes.sponza_like()
+    w, h = 320, 180
+    ref = oracle_mod.render_frame(oracle_mod.PackedScene(scene), w, h, mode=1)
+    gpu = _render_gpu(gpu_ctx, scene, w, h, mode=1)
+    _assert_bit_exact(gpu, ref)
+    assert (gpu["prim"] != 0xFFFFFFFF).mean() > 0.95
+
+
+def test_dispatch_tile_sequence_equals_render(gpu_ctx, oracle_mod):
+    """The drop-in path: one rt_dispatch_tile per (tile, channel) exactly as src/compute.rs:169-251 issues
+    dispatches, with byte-for-byte reference buffers (rt_upload_scene_packed)."""
+    scene = scenes.default_scene()
+    packed = oracle_mod.PackedScene(scene)  # metadata buffer incl. a reference-format BVH
+    w, h = 300, 200
+    gpu_ctx.upload_scene(scene)
+    gpu_ctx.render(w, h, scene.camera)
+    want = gpu_ctx.read_rgba8_channels()
+    with type(gpu_ctx)() as ctx2:
+        ctx2.upload_scene_packed(packed.metadata, packed.offsets, packed.tri_bufs, packed.triangles_per_buffer, scene.materials)
+        tx, ty = H.tile_count(w, h)
+        for tile in range(tx * ty):
+            ox, oy = (tile % tx) * 128, (tile // tx) * 128
+            for ch in range(3):
+                ctx2.dispatch_tile(packed.push_constants(w, h, channel=ch, tile_offset=(ox, oy)))
+        got = ctx2.read_rgba8_channels()
+        comb = ctx2.read_rgba8_combined()
+    for c in range(3):
+        np.testing.assert_array_equal(got[c], want[c])
+    ref = oracle_mod.render_frame(packed, w, h)
+    np.testing.assert_array_equal(comb, ref["combined"])
+
+
+def test_dispatch_tile_partial_tile_and_channel_isolation(gpu_ctx, oracle_mod):
+    """K6 on the device: texels outside tile_size / the image are untouched; a channel dispatch leaves the
+    other two textures alone; channel > 2 is rejected like get_compute_bind_group."""
+    scene = scenes.empty_scene()
+    packed = oracle_mod.PackedScene(scene)
+    w, h = 200, 100
+    gpu_ctx.upload_scene(scene)
+    pc = packed.push_constants(w, h, channel=1, mode=1, tile_offset=(128, 0), tile_size=(72, 100))
+    gpu_ctx.dispatch_tile(pc)
+    r, g, b = gpu_ctx.read_rgba8_channels()
+    assert (r == 0).all() and (b == 0).all()
+    assert (g[:, 128:] == np.array([0, 51, 0, 255], np.uint8)).all() and (g[:, :128] == 0).all()
+    img = np.zeros((h, w, 4), np.uint8)
+    oracle_mod.dispatch(packed, pc, img)
+    np.testing.assert_array_equal(g, img)
+    pc = packed.push_constants(w, h, channel=0, mode=1, tile_offset=(0, 0), tile_size=(20, 10))
+    gpu_ctx.dispatch_tile(pc)
+    r, _, _ = gpu_ctx.read_rgba8_channels()
+    assert (r[..., 3] == 255).sum() == 200
+    bad = packed.push_constants(w, h, channel=3)
+    with pytest.raises(Exception, match="BAD_ARG"):
+        gpu_ctx.dispatch_tile(bad)
+
+
+def test_mode1_pass_beyond_max_bounce_writes_black(gpu_ctx, oracle_mod):
+    scene = scenes.default_scene()
+    packed = oracle_mod.PackedScene(scene)
+    gpu_ctx.upload_scene(scene)
+    for ch in range(3):
+        gpu_ctx.dispatch_tile(packed.push_constants(64, 64, channel=ch, mode=1, cur_bounce=5, max_bounce=4, tile_size=(64, 64)))
+    comb = gpu_ctx.read_rgba8_combined()
+    assert (comb[..., :3] == 0).all() and (comb[..., 3] == 255).all()
+    for ch in range(3):
+        gpu_ctx.dispatch_tile(packed.push_constants(64, 64, channel=ch, mode=1, cur_bounce=2, max_bounce=4, tile_size=(64, 64)))
+    ref = oracle_mod.render_frame(packed, 64, 64, mode=1, cur_bounce=2)
+    np.testing.assert_array_equal(gpu_ctx.read_rgba8_combined(), ref["combined"])
+
+
+def test_tile_partition_union_equals_full_frame(gpu_ctx):
+    """Multi-GPU partition (tile i -> rank i mod N): the union of the ranks' tiles is the full frame."""
+    scene = scenes.random_soup(3000, seed=9, n_spheres=2)
+    w, h = 400, 300  # 4 x 3 tiles with ragged right/bottom edges
+    gpu_ctx.upload_scene(scene)
+    gpu_ctx.render(w, h, scene.camera)
+    full = gpu_ctx.read_rgb32f()
+    for world in (2, 3, 8):
+        acc = np.zeros_like(full)
+        cover = np.zeros((h, w), int)
+        rays = 0
+        for rank in range(world):
+            with type(gpu_ctx)() as c:
+                c.upload_scene(scene)
+                st = c.render(w, h, scene.camera, tile_rank=rank, tile_world=world)
+                part = c.read_rgb32f()
+                prim, _ = c.read_hits()
+            rays += st["rays"]
+            tx, ty = H.tile_count(w, h)
+            for tile in range(rank, tx * ty, world):
+                ox, oy = (tile % tx) * 128, (tile // tx) * 128
+                cover[oy:oy + 128, ox:ox + 128] += 1
+                acc[oy:oy + 128, ox:ox + 128] = part[oy:oy + 128, ox:ox + 128]
+        assert (cover == 1).all() and rays == w * h
+        np.testing.assert_array_equal(acc.view(np.uint32), full.view(np.uint32))
+
+
+def test_counters_and_stats(gpu_ctx, oracle_mod):
+    scene = scenes.random_soup(5000, seed=4, size=0.3)
+    gpu_ctx.upload_scene(scene)
+    st = gpu_ctx.render(256, 160, scene.camera, counters=True)
+    assert st["rays"] == st["pixels"] == 256 * 160 and st["kernel_ms"] > 0
+    assert st["node_bytes"] == 64 and st["tri_bytes"] == 48 and st["bvh_depth"] <= 32
+    ref = oracle_mod.render_frame(oracle_mod.PackedScene(scene), 256, 160)
+    # ordered traversal with culling visits far fewer nodes than the reference's pop-then-test walk
+    assert 0 < st["node_visits"] < ref["counters"]["node_visits"]
+    assert 0 < st["tri_tests"] <= ref["counters"]["tri_tests"]
+    st2 = gpu_ctx.render(256, 160, scene.camera)
+    assert st2["node_visits"] == 0 and st2["tri_tests"] == 0
+
+
+def test_error_paths(gpu_ctx):
+    scene = scenes.single_triangle()
+    with pytest.raises(Exception, match="NOT_UPLOADED"):
+        gpu_ctx.render(8, 8, scene.camera)
+    bad = scenes.single_triangle()
+    bad.triangles["v2_index"] = 99
+    with pytest.raises(Exception, match="BAD_ARG"):
+        gpu_ctx.upload_scene(bad)
+    gpu_ctx.upload_scene(scene)
+    with pytest.raises(Exception, match="BAD_ARG"):
+        gpu_ctx.render(0, 8, scene.camera)
+    with pytest.raises(Exception, match="BAD_ARG"):
+        gpu_ctx.render(8, 8, scene.camera, tile_rank=2, tile_world=2)
+    gpu_ctx.render(8, 8, scene.camera)
+    # NaN vertices can never be hit (every Möller–Trumbore comparison fails); they are dropped, not an error
+    nan = scenes.single_triangle()
+    nan.vertices["position"][0, 0] = np.nan
+    gpu_ctx.upload_scene(nan)
+    gpu_ctx.render(16, 16, nan.camera)
+    prim, _ = gpu_ctx.read_hits()
+    assert (prim == 0xFFFFFFFF).all()
+
+
+def test_full_size_properties_sponza_1080p(gpu_ctx):
+    """BASELINE size (1920x1080): size-independent properties instead of a CPU render —
+    idempotence, mode 0 / mode 1 agree wherever something is hit, sky exactly where mode 0 is black-miss,
+    coverage of the enclosed atrium, and the three channel textures are the unorm8 of the float image."""
+    scene = scenes.sponza_like()
+    gpu_ctx.upload_scene(scene)
+    w, h = 1920, 1080
+    gpu_ctx.render(w, h, scene.camera, mode=0)
+    rgb0, (prim0, t0), ch0 = gpu_ctx.read_rgb32f(), gpu_ctx.read_hits(), gpu_ctx.read_rgba8_channels()
+    gpu_ctx.render(w, h, scene.camera, mode=0)
+    np.testing.assert_array_equal(gpu_ctx.read_rgb32f().view(np.uint32), rgb0.view(np.uint32))
+    gpu_ctx.render(w, h, scene.camera, mode=1)
+    rgb1, (prim1, t1) = gpu_ctx.read_rgb32f(), gpu_ctx.read_hits()
+    hit = prim0 != 0xFFFFFFFF
+    assert hit.mean() > 0.99
+    np.testing.assert_array_equal(prim0, prim1)  # double vs single normalisation never changes the hit here?
+    np.testing.assert_allclose(rgb1[hit], rgb0[hit], atol=1e-5)
+    assert (rgb0[~hit] == 0).all() and (rgb1[~hit] == np.array([0.1, 0.2, 0.3], np.float32)).all()
+    assert np.isfinite(rgb0).all() and (t0[hit] > 1e-5).all()
+    q = np.floor(np.clip(rgb0, 0, 1) * np.float32(255.0) + np.float32(0.5)).astype(np.uint8)
+    for c in range(3):
+        np.testing.assert_array_equal(ch0[c][..., c], q[..., c])
+        assert (ch0[c][..., 3] == 255).all() and (ch0[c][..., (c + 1) % 3] == 0).all()
