@@ -91,15 +91,28 @@ def barrier_sync(dist, torch_cuda):
         torch_cuda.synchronize()
 
 
+def available_cpus():
+    """CPUs this process may actually use: cgroup quota if set, else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(scene, camera, sample, mode):
     """The oracle (CPU restatement of the reference kernel, reference-format chunked BVH, no t-culling —
     what the reference's kernel executes per ray) timed on this host's cores on a bounded sample."""
     import oracle
     w, h = (int(v) for v in sample.split("x"))
-    cores = os.cpu_count() or 1
+    cores = available_cpus()
     packed = oracle.PackedScene(scene)
     t0 = time.perf_counter()
-    r = oracle.render_frame(packed, w, h, camera=camera, mode=mode, threads=cores, want_rgba8=False)
+    # 32x32 work items so every thread stays busy; the image does not depend on the tile size
+    r = oracle.render_frame(packed, w, h, camera=camera, mode=mode, threads=cores, want_rgba8=False, tile_size=32)
     dt = time.perf_counter() - t0
     rays = r["counters"]["rays"]
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",

@@ -131,7 +131,8 @@ class Context:
     def dispatch_tile(self, pc):
         pcb = np.ascontiguousarray(pc)
         self._check(self.lib.rt_dispatch_tile(self._h, _p(pcb)))
-        self.width, self.height = int(pcb["resolution"][0]), int(pcb["resolution"][1])
+        res = pcb["resolution"].reshape(-1)
+        self.width, self.height = int(res[0]), int(res[1])
 
     # -- read-back -------------------------------------------------------------------
     def read_rgb32f(self):
