@@ -98,9 +98,11 @@ def available_cpus():
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
         if quota != "max":
             n = min(n, max(1, int(int(quota) / int(period))))
+        return max(1, n)
     except Exception:
         pass
-    return max(1, n)
+    # no quota visible: a GPU box exposes every host CPU but grants a share of 16 per GPU
+    return max(1, min(n, int(os.environ.get("RT_BENCH_CPU_THREADS", "16"))))
 
 
 def cpu_baseline(scene, camera, sample, mode):
