@@ -112,6 +112,7 @@ struct DevFrame {
     uint32_t channel_mask;                           // bit c set: write channel texture c (rt_dispatch_tile writes one)
     uint32_t cur_bounce, max_bounce;                 // mode 1 pass selection (shader/src/lib.rs:117-121)
     uint32_t spp, frame_seed;
+    uint32_t flags;                                  // RT_FLAG_* of rt_render_params
     // when single_tile != 0 the launch covers exactly one tile given explicitly (rt_dispatch_tile)
     uint32_t single_tile, tile_off_x, tile_off_y, tile_w, tile_h;
 };
@@ -121,7 +122,7 @@ struct DevTargets {
     uint8_t* chan[3];    // three Rgba8Unorm channel textures, width*height*4 bytes each
     uint32_t* prim_id;   // per-pixel closest primitive (modes 0/1)
     float* hit_t;        // per-pixel hit distance       (modes 0/1)
-    unsigned long long* counters; // [0] rays [1] node visits [2] tri tests [3] primary rays
+    unsigned long long* counters; // [0] rays [1] node visits [2] tri tests [3] camera [4] continuation [5] shadow segments
 };
 
 #endif

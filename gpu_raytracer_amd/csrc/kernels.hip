@@ -144,7 +144,8 @@ __device__ __forceinline__ void test_triangle(const DevTri* __restrict__ tris, u
 // stack[k * 64 + l]): ds_read/write_b32 with consecutive lanes on consecutive banks.
 // Depth cannot exceed RT_DEV_STACK_DEPTH: the builder bounds the tree depth.
 // ------------------------------------------------------------------------------------
-template <bool COUNT>
+// ANY_HIT (shadow segments of the extended mode): return at the first accepted triangle.
+template <bool COUNT, bool ANY_HIT>
 __device__ __forceinline__ void traverse(const DevScene& sc, V3 o, V3 d, uint32_t* __restrict__ stack, Hit& hit, Counts& cnt) {
     if (sc.n_tris == 0) return;
     const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); // ray_aabb_intersect recomputes this per node (:152)
@@ -193,6 +194,7 @@ __device__ __forceinline__ void traverse(const DevScene& sc, V3 o, V3 d, uint32_
             for (uint32_t i = 0; i < count; i++) {
                 if (COUNT) cnt.tris++;
                 test_triangle(sc.tris, start + i, o, d, hit);
+                if (ANY_HIT && hit.prim != RT_PRIM_MISS) return;
             }
         }
         if (sp == 0) break;
@@ -210,7 +212,7 @@ __device__ __forceinline__ Hit find_closest(const DevScene& sc, V3 o, V3 d, uint
     hit.prim = RT_PRIM_MISS;
     hit.slot = 0;
     test_spheres(sc, o, d, hit);
-    traverse<COUNT>(sc, o, d, stack, hit, cnt);
+    traverse<COUNT, false>(sc, o, d, stack, hit, cnt);
     return hit;
 }
 
@@ -229,36 +231,45 @@ __device__ __forceinline__ V3 evaluate_brdf(const DevMaterial& m, float intensit
     return metallic_contrib * is_metallic + dielectric_contrib * (1.0f - is_metallic);
 }
 
+// calculate_light_contribution (lighting.rs:50-94) for one light.  Also returns the direction and
+// length of the segment toward the light (used by the extended mode's shadow rays).
+__device__ __forceinline__ V3 light_contribution(const DevLight& L, const DevMaterial& m, V3 point, V3 normal, V3& to_light_dir,
+                                                 float& to_light_dist) {
+    V3 ldir = ld3(L.direction);
+    V3 dir_light_dir = -normalize(ldir); // lighting.rs:103
+    float dir_intensity = fmaxf(dot(normal, dir_light_dir), 0.0f) * L.intensity;
+    V3 to_light = ld3(L.position) - point; // lighting.rs:120-122
+    float distance = length(to_light);
+    V3 pld = normalize(to_light);
+    float att = f16_round_trip(1.0f / (1.0f + distance * distance * 0.01f)); // :125-127
+    float point_intensity = fmaxf(dot(normal, pld), 0.0f) * L.intensity * att;
+    float spot_factor = fmaxf(dot(-normalize(ldir), pld), 0.0f); // :132
+    float spot_intensity = point_intensity * spot_factor;
+    float is_dir = (L.light_type == 0) ? 1.0f : 0.0f;
+    float is_point = (L.light_type == 1) ? 1.0f : 0.0f;
+    float is_spot = (L.light_type == 2) ? 1.0f : 0.0f;
+    float final_i = dir_intensity * is_dir + point_intensity * is_point + spot_intensity * is_spot;
+    V3 brdf = evaluate_brdf(m, final_i);
+    float valid = (final_i > 0.0f) ? 1.0f : 0.0f; // index_valid is always 1 inside the loop
+    to_light_dir = (L.light_type == 0) ? dir_light_dir : pld;
+    to_light_dist = (L.light_type == 0) ? RT_F32_MAX : distance;
+    return brdf * ld3(L.color) * valid;
+}
+
 __device__ __forceinline__ V3 calculate_lighting(const DevScene& sc, const DevMaterial& m, V3 point, V3 normal) {
     V3 total = v3(0.0f, 0.0f, 0.0f);
     total = total + ld3(m.albedo) * 0.1f; // ambient, lighting.rs:30-31
     for (uint32_t li = 0; li < sc.n_lights; li++) {
-        const DevLight& L = sc.lights[li];
-        V3 ldir = ld3(L.direction);
-        V3 dir_light_dir = -normalize(ldir); // lighting.rs:103
-        float dir_intensity = fmaxf(dot(normal, dir_light_dir), 0.0f) * L.intensity;
-        V3 to_light = ld3(L.position) - point; // lighting.rs:120-122
-        float distance = length(to_light);
-        V3 pld = normalize(to_light);
-        float att = f16_round_trip(1.0f / (1.0f + distance * distance * 0.01f)); // :125-127
-        float point_intensity = fmaxf(dot(normal, pld), 0.0f) * L.intensity * att;
-        float spot_factor = fmaxf(dot(-normalize(ldir), pld), 0.0f); // :132
-        float spot_intensity = point_intensity * spot_factor;
-        float is_dir = (L.light_type == 0) ? 1.0f : 0.0f;
-        float is_point = (L.light_type == 1) ? 1.0f : 0.0f;
-        float is_spot = (L.light_type == 2) ? 1.0f : 0.0f;
-        float final_i = dir_intensity * is_dir + point_intensity * is_point + spot_intensity * is_spot;
-        V3 brdf = evaluate_brdf(m, final_i);
-        float valid = (final_i > 0.0f) ? 1.0f : 0.0f; // index_valid is always 1 inside the loop
-        total = total + brdf * ld3(L.color) * valid;
+        V3 sd;
+        float st;
+        total = total + light_contribution(sc.lights[li], m, point, normal, sd, st);
     }
     return total + ld3(m.emission);
 }
 
-__device__ __forceinline__ V3 shade_hit(const DevScene& sc, const Hit& hit, V3 o, V3 d) {
-    V3 point = o + d * hit.t; // Ray::at, ray.rs:56-58
-    V3 normal;
-    uint32_t material_id;
+// hit -> (point, geometric normal, material id)
+__device__ __forceinline__ void hit_geometry(const DevScene& sc, const Hit& hit, V3 o, V3 d, V3& point, V3& normal, uint32_t& material_id) {
+    point = o + d * hit.t; // Ray::at, ray.rs:56-58
     if (hit.prim & RT_PRIM_SPHERE_FLAG) {
         const DevSphere& s = sc.spheres[hit.slot];
         normal = normalize(point - ld3(s.center)); // intersection.rs:80
@@ -271,19 +282,28 @@ __device__ __forceinline__ V3 shade_hit(const DevScene& sc, const Hit& hit, V3 o
         normal = normalize(cross(e1, e2)); // geometric, winding dependent, never flipped (intersection.rs:132)
         material_id = __float_as_uint(q2.y);
     }
+}
+
+// The transmission mix of calculate_shading (lib.rs:323-337) for all three channel passes at once.
+__device__ __forceinline__ V3 transmission_mix(const DevMaterial& m, V3 lighting, float tf) {
+    // per channel c: ior_c = ior + {-0.018, 0, +0.035}[c]; disp = (ior_c - 1) / (ior - 1)   (material.rs:42-58, lib.rs:326-334)
+    float disp_r = ((m.ior + -0.018f) - 1.0f) / (m.ior - 1.0f);
+    float disp_g = ((m.ior + 0.0f) - 1.0f) / (m.ior - 1.0f);
+    float disp_b = ((m.ior + 0.035f) - 1.0f) / (m.ior - 1.0f);
+    float keep = 1.0f - tf;
+    return v3(lighting.x * keep + (0.2f * disp_r) * tf, lighting.y * keep + (0.2f * disp_g) * tf,
+              lighting.z * keep + (0.3f * disp_b) * tf);
+}
+
+__device__ __forceinline__ V3 shade_hit(const DevScene& sc, const Hit& hit, V3 o, V3 d) {
+    V3 point, normal;
+    uint32_t material_id;
+    hit_geometry(sc, hit, o, d, point, normal, material_id);
     if (material_id >= sc.n_materials) return v3(1.0f, 0.0f, 1.0f); // magenta, lib.rs:307-309
     const DevMaterial m = sc.materials[material_id];
     V3 lighting = calculate_lighting(sc, m, point, normal);
     float tf = fminf(fmaxf(m.transmission, 0.0f), 1.0f); // lib.rs:323
-    if (tf > 0.0f) {
-        // per channel c: ior_c = ior + {-0.018, 0, +0.035}[c]; disp = (ior_c - 1) / (ior - 1)   (material.rs:42-58, lib.rs:326-334)
-        float disp_r = ((m.ior + -0.018f) - 1.0f) / (m.ior - 1.0f);
-        float disp_g = ((m.ior + 0.0f) - 1.0f) / (m.ior - 1.0f);
-        float disp_b = ((m.ior + 0.035f) - 1.0f) / (m.ior - 1.0f);
-        float keep = 1.0f - tf;
-        return v3(lighting.x * keep + (0.2f * disp_r) * tf, lighting.y * keep + (0.2f * disp_g) * tf,
-                  lighting.z * keep + (0.3f * disp_b) * tf);
-    }
+    if (tf > 0.0f) return transmission_mix(m, lighting, tf);
     return lighting;
 }
 
@@ -369,6 +389,244 @@ __global__ __launch_bounds__(WAVE) void k_render_reference(DevScene sc, DevFrame
     }
 }
 
+
+// ====================================================================================
+// Extended mode (RT_MODE_EXTENDED): jittered samples, shadow rays and real bounces, built on
+// the reference's declared-but-stub wavefront API (SimpleRng wavefront.rs:46-72, pixel seed
+// lib.rs:103-105, generate_camera_ray wavefront.rs:75-112, WavefrontRay types and epsilon
+// shared/src/lib.rs:833-956, apply_russian_roulette shared/src/lib.rs:969-978).  The rules are
+// stated in DESIGN.md "Extended mode" and, executable, in oracle/rt_oracle.cpp (ExtKernel);
+// this is the same arithmetic in the same order.
+// ====================================================================================
+struct SimpleRng {
+    uint32_t seed;
+    __device__ __forceinline__ uint32_t next_u32() {
+        seed = seed * 1664525u + 1013904223u;
+        return seed;
+    }
+    __device__ __forceinline__ float next_f32() { return (float)(next_u32() >> 8) / 16777216.0f; }
+};
+
+__device__ __forceinline__ SimpleRng rng_for(uint32_t pixel_seed, uint32_t sample) {
+    uint32_t h = pixel_seed + sample * 0x9E3779B9u;
+    h ^= h >> 16;
+    h *= 0x7FEB352Du;
+    h ^= h >> 15;
+    h *= 0x846CA68Bu;
+    h ^= h >> 16;
+    return SimpleRng{h};
+}
+
+// sin/cos(2*pi*u) as explicit-fma polynomials: identical bits on the host oracle and here.
+__device__ __forceinline__ void sincos_2pi(float u, float& s_out, float& c_out) {
+    float f4 = u * 4.0f;
+    float qf = floorf(f4);
+    int q = (int)qf;
+    float x = (f4 - qf) * 1.57079632679489661923f;
+    float x2 = x * x;
+    float sp = __builtin_fmaf(x2, -2.50521083854417187751e-8f, 2.75573192239858906526e-6f);
+    sp = __builtin_fmaf(x2, sp, -1.98412698412698412698e-4f);
+    sp = __builtin_fmaf(x2, sp, 8.33333333333333333333e-3f);
+    sp = __builtin_fmaf(x2, sp, -1.66666666666666666667e-1f);
+    sp = __builtin_fmaf(x2, sp, 1.0f);
+    float sn = x * sp;
+    float cp = __builtin_fmaf(x2, 2.08767569878680989792e-9f, -2.75573192239858906526e-7f);
+    cp = __builtin_fmaf(x2, cp, 2.48015873015873015873e-5f);
+    cp = __builtin_fmaf(x2, cp, -1.38888888888888888889e-3f);
+    cp = __builtin_fmaf(x2, cp, 4.16666666666666666667e-2f);
+    cp = __builtin_fmaf(x2, cp, -0.5f);
+    float cs = __builtin_fmaf(x2, cp, 1.0f);
+    switch (q & 3) {
+        case 0: s_out = sn; c_out = cs; break;
+        case 1: s_out = cs; c_out = -sn; break;
+        case 2: s_out = -sn; c_out = -cs; break;
+        default: s_out = -cs; c_out = sn; break;
+    }
+}
+
+__device__ __forceinline__ V3 unit_vector(float u1, float u2) {
+    float z = 1.0f - 2.0f * u1;
+    float r = sqrtf(fmaxf(0.0f, 1.0f - z * z));
+    float sn, cs;
+    sincos_2pi(u2, sn, cs);
+    return v3(r * cs, r * sn, z);
+}
+
+#define EXT_EPS 0.001f /* WavefrontRay::t_min (shared/src/lib.rs:854) as the origin offset */
+
+struct SegCounts {
+    uint32_t camera, continuation, shadow;
+};
+
+// any hit in (1e-5, tmax)?  Spheres first, then the BVH with early exit.
+template <bool COUNT>
+__device__ __forceinline__ bool occluded(const DevScene& sc, V3 o, V3 d, float tmax, uint32_t* stack, Counts& cnt) {
+    Hit h;
+    h.t = tmax;
+    h.prim = RT_PRIM_MISS;
+    h.slot = 0;
+    test_spheres(sc, o, d, h);
+    if (h.prim != RT_PRIM_MISS) return true;
+    traverse<COUNT, true>(sc, o, d, stack, h, cnt);
+    return h.prim != RT_PRIM_MISS;
+}
+
+template <bool COUNT>
+__device__ __forceinline__ V3 ext_direct(const DevScene& sc, const DevMaterial& m, V3 point, V3 normal, bool ambient, bool shadows,
+                                         uint32_t* stack, Counts& cnt, SegCounts& seg) {
+    V3 total = v3(0.0f, 0.0f, 0.0f);
+    if (ambient) total = total + ld3(m.albedo) * 0.1f;
+    for (uint32_t li = 0; li < sc.n_lights; li++) {
+        V3 sdir;
+        float sdist;
+        V3 contrib = light_contribution(sc.lights[li], m, point, normal, sdir, sdist);
+        if (!(contrib.x != 0.0f || contrib.y != 0.0f || contrib.z != 0.0f)) {
+            total = total + contrib;
+            continue;
+        }
+        if (shadows) {
+            seg.shadow++;
+            if (occluded<COUNT>(sc, point + normal * EXT_EPS, sdir, sdist, stack, cnt)) continue;
+        }
+        total = total + contrib;
+    }
+    return total + ld3(m.emission);
+}
+
+template <bool COUNT>
+__device__ __forceinline__ V3 ext_trace_path(const DevScene& sc, const DevFrame& fr, uint32_t px, uint32_t py, uint32_t sample,
+                                             uint32_t* stack, Counts& cnt, SegCounts& seg) {
+    SimpleRng rng = rng_for(fr.frame_seed + px + py * fr.width, sample);
+    float jx = 0.5f, jy = 0.5f;
+    if (fr.spp > 1) {
+        jx = rng.next_f32();
+        jy = rng.next_f32();
+    }
+    V3 o, d;
+    camera_ray(fr.cam, (float)px + jx, (float)py + jy, true, o, d);
+    V3 radiance = v3(0.0f, 0.0f, 0.0f);
+    V3 throughput = v3(1.0f, 1.0f, 1.0f);
+    uint32_t channel = 3;
+    const bool shadows = (fr.flags & 2u) == 0;
+    for (uint32_t depth = 0;; depth++) {
+        if (depth == 0) seg.camera++; else seg.continuation++;
+        Hit hit = find_closest<COUNT>(sc, o, d, stack, cnt);
+        if (hit.prim == RT_PRIM_MISS) {
+            radiance = radiance + v3(0.1f, 0.2f, 0.3f) * throughput;
+            break;
+        }
+        V3 point, normal;
+        uint32_t material_id;
+        hit_geometry(sc, hit, o, d, point, normal, material_id);
+        if (material_id >= sc.n_materials) {
+            radiance = radiance + v3(1.0f, 0.0f, 1.0f) * throughput;
+            break;
+        }
+        const DevMaterial m = sc.materials[material_id];
+        float tf = fminf(fmaxf(m.transmission, 0.0f), 1.0f);
+        bool terminal = depth >= fr.max_bounce;
+        V3 lighting = ext_direct<COUNT>(sc, m, point, normal, terminal, shadows, stack, cnt, seg);
+        if (terminal) {
+            V3 out = lighting;
+            if (tf > 0.0f) out = transmission_mix(m, lighting, tf);
+            radiance = radiance + out * throughput;
+            break;
+        }
+        radiance = radiance + (lighting * (1.0f - tf)) * throughput;
+
+        bool front = dot(normal, d) < 0.0f;
+        V3 nf = front ? normal : -normal;
+        bool transmit = false;
+        if (tf > 0.0f) transmit = rng.next_f32() < tf;
+        V3 ndir, norigin;
+        V3 albedo = ld3(m.albedo);
+        if (transmit) {
+            if (channel == 3) {
+                uint32_t c = (uint32_t)(rng.next_f32() * 3.0f);
+                channel = c < 2 ? c : 2;
+                throughput = v3(channel == 0 ? throughput.x * 3.0f : 0.0f, channel == 1 ? throughput.y * 3.0f : 0.0f,
+                                channel == 2 ? throughput.z * 3.0f : 0.0f);
+            }
+            float offs = channel == 0 ? -0.018f : (channel == 1 ? 0.0f : 0.035f); // material.rs:47-52
+            float ior_c = m.ior + offs;
+            float eta = front ? (1.0f / ior_c) : ior_c;
+            float cos_i = -dot(nf, d);
+            float sin2_t = eta * eta * (1.0f - cos_i * cos_i);
+            if (sin2_t > 1.0f) {
+                ndir = d - nf * (2.0f * dot(d, nf));
+                norigin = point + nf * EXT_EPS;
+            } else {
+                float cos_t = sqrtf(1.0f - sin2_t);
+                ndir = d * eta + nf * (eta * cos_i - cos_t);
+                norigin = point - nf * EXT_EPS;
+            }
+            ndir = normalize(ndir);
+            throughput = throughput * albedo;
+        } else if (m.metallic > 0.5f) {
+            float u1 = rng.next_f32(), u2 = rng.next_f32();
+            V3 r = d - nf * (2.0f * dot(d, nf));
+            ndir = normalize(r + unit_vector(u1, u2) * m.roughness);
+            if (!(dot(ndir, nf) > 0.0f)) break;
+            norigin = point + nf * EXT_EPS;
+            throughput = throughput * albedo;
+        } else {
+            float u1 = rng.next_f32(), u2 = rng.next_f32();
+            V3 w = nf + unit_vector(u1, u2);
+            if (dot(w, w) < 1e-12f) w = nf;
+            ndir = normalize(w);
+            norigin = point + nf * EXT_EPS;
+            throughput = throughput * albedo;
+        }
+        if (depth >= 2) {
+            float p = fminf(fmaxf(fmaxf(fmaxf(throughput.x, throughput.y), throughput.z), 0.05f), 1.0f);
+            if (rng.next_f32() > p) break;
+            throughput = v3(throughput.x / p, throughput.y / p, throughput.z / p);
+        }
+        o = norigin;
+        d = ndir;
+    }
+    return radiance;
+}
+
+__device__ __forceinline__ unsigned long long wave_sum(uint32_t v) {
+    unsigned long long s = v;
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, WAVE);
+    return s;
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(WAVE) void k_render_extended(DevScene sc, DevFrame fr, DevTargets tg) {
+    __shared__ uint32_t s_stack[RT_DEV_STACK_DEPTH * WAVE];
+    PixelCoord px = block_pixel(fr);
+    uint32_t* stack = s_stack + threadIdx.x;
+    Counts cnt = {0u, 0u};
+    SegCounts seg = {0u, 0u, 0u};
+    if (px.valid) {
+        V3 sum = v3(0.0f, 0.0f, 0.0f);
+        for (uint32_t s = 0; s < fr.spp; s++) sum = sum + ext_trace_path<COUNT>(sc, fr, px.x, px.y, s, stack, cnt, seg);
+        float n = (float)fr.spp;
+        V3 color = v3(sum.x / n, sum.y / n, sum.z / n);
+        const size_t pix = (size_t)px.y * fr.width + px.x;
+        if (tg.rgba32f) reinterpret_cast<float4*>(tg.rgba32f)[pix] = make_float4(color.x, color.y, color.z, 1.0f);
+        if (tg.chan[0]) reinterpret_cast<uint32_t*>(tg.chan[0])[pix] = unorm8(color.x) | 0xFF000000u;
+        if (tg.chan[1]) reinterpret_cast<uint32_t*>(tg.chan[1])[pix] = (unorm8(color.y) << 8) | 0xFF000000u;
+        if (tg.chan[2]) reinterpret_cast<uint32_t*>(tg.chan[2])[pix] = (unorm8(color.z) << 16) | 0xFF000000u;
+    }
+    // segment counts are part of the result (rt_stats.rays): one atomic per wave and counter
+    unsigned long long c0 = wave_sum(seg.camera), c1 = wave_sum(seg.continuation), c2 = wave_sum(seg.shadow);
+    unsigned long long n0 = COUNT ? wave_sum(cnt.nodes) : 0ull, n1 = COUNT ? wave_sum(cnt.tris) : 0ull;
+    if (threadIdx.x == 0 && tg.counters) {
+        atomicAdd(&tg.counters[0], c0 + c1 + c2);
+        atomicAdd(&tg.counters[3], c0);
+        atomicAdd(&tg.counters[4], c1);
+        atomicAdd(&tg.counters[5], c2);
+        if (COUNT) {
+            atomicAdd(&tg.counters[1], n0);
+            atomicAdd(&tg.counters[2], n1);
+        }
+    }
+}
+
 } // namespace
 
 namespace rt {
@@ -386,6 +644,17 @@ hipError_t launch_render_reference(const DevScene& sc, const DevFrame& fr, const
         hipLaunchKernelGGL(k_render_reference<true>, grid, block, 0, stream, sc, fr, tg);
     else
         hipLaunchKernelGGL(k_render_reference<false>, grid, block, 0, stream, sc, fr, tg);
+    return hipGetLastError();
+}
+
+hipError_t launch_render_extended(const DevScene& sc, const DevFrame& fr, const DevTargets& tg, bool counters, hipStream_t stream) {
+    uint32_t n_tiles = fr.n_owned_tiles;
+    if (n_tiles == 0) return hipSuccess;
+    dim3 grid(n_tiles * blocks_per_tile(fr.tile_size)), block(WAVE);
+    if (counters)
+        hipLaunchKernelGGL(k_render_extended<true>, grid, block, 0, stream, sc, fr, tg);
+    else
+        hipLaunchKernelGGL(k_render_extended<false>, grid, block, 0, stream, sc, fr, tg);
     return hipGetLastError();
 }
 

@@ -273,13 +273,17 @@ int run_frame(rt_ctx* ctx, DevFrame fr, bool counters, uint32_t world, uint32_t 
             d.tile_stride = stride;
             d.n_owned = f.n_owned_tiles;
         }
-        HIPCHK(ctx, hipMemsetAsync(d.counters, 0, 4 * sizeof(unsigned long long), d.stream));
+        HIPCHK(ctx, hipMemsetAsync(d.counters, 0, 8 * sizeof(unsigned long long), d.stream));
         HIPCHK(ctx, hipEventRecord(d.ev0, d.stream));
-        HIPCHK(ctx, rt::launch_render_reference(scene_for(ctx, d), f, targets_for(d), counters, d.stream));
+        if (f.mode == RT_MODE_EXTENDED)
+            HIPCHK(ctx, rt::launch_render_extended(scene_for(ctx, d), f, targets_for(d), counters, d.stream));
+        else
+            HIPCHK(ctx, rt::launch_render_reference(scene_for(ctx, d), f, targets_for(d), counters, d.stream));
         HIPCHK(ctx, hipEventRecord(d.ev1, d.stream));
     }
     double kernel_ms = 0.0;
-    unsigned long long cnt[4] = {0, 0, 0, 0};
+    unsigned long long cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool extended = fr.mode == RT_MODE_EXTENDED;
     uint64_t pixels = 0;
     for (size_t j = 0; j < nd; j++) {
         DeviceState& d = ctx->devs[j];
@@ -288,10 +292,10 @@ int run_frame(rt_ctx* ctx, DevFrame fr, bool counters, uint32_t world, uint32_t 
         float ms = 0.0f;
         HIPCHK(ctx, hipEventElapsedTime(&ms, d.ev0, d.ev1));
         kernel_ms = std::max(kernel_ms, (double)ms);
-        if (counters) {
-            unsigned long long c[4];
+        if (counters || extended) {
+            unsigned long long c[8];
             HIPCHK(ctx, hipMemcpy(c, d.counters, sizeof c, hipMemcpyDeviceToHost));
-            for (int k = 0; k < 4; k++) cnt[k] += c[k];
+            for (int k = 0; k < 8; k++) cnt[k] += c[k];
         }
         if (single_tile) {
             pixels += (uint64_t)std::min(fr.tile_w, fr.width - std::min(fr.width, fr.tile_off_x)) *
@@ -307,8 +311,16 @@ int run_frame(rt_ctx* ctx, DevFrame fr, bool counters, uint32_t world, uint32_t 
     rt_stats& st = ctx->stats;
     st.pixels = pixels;
     bool traced = fr.mode == RT_MODE_LEGACY || fr.cur_bounce <= fr.max_bounce;
-    st.rays = traced ? pixels : 0; // modes 0/1: one segment per pixel
-    st.primary_rays = st.rays;
+    if (extended) { // segments counted on the device
+        st.rays = cnt[0];
+        st.primary_rays = cnt[3];
+        st.continuation_rays = cnt[4];
+        st.shadow_rays = cnt[5];
+    } else {
+        st.rays = traced ? pixels : 0; // modes 0/1: one segment per pixel
+        st.primary_rays = st.rays;
+        st.continuation_rays = st.shadow_rays = 0;
+    }
     st.node_visits = counters ? cnt[1] : 0;
     st.tri_tests = counters ? cnt[2] : 0;
     st.kernel_ms = kernel_ms;
@@ -347,7 +359,7 @@ int rt_create(rt_ctx** out, const int* device_ids, int n_devices) {
         }
         if ((e = hipSetDevice(d.device)) != hipSuccess || (e = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking)) != hipSuccess ||
             (e = hipEventCreate(&d.ev0)) != hipSuccess || (e = hipEventCreate(&d.ev1)) != hipSuccess ||
-            (e = hipMalloc((void**)&d.counters, 4 * sizeof(unsigned long long))) != hipSuccess) {
+            (e = hipMalloc((void**)&d.counters, 8 * sizeof(unsigned long long))) != hipSuccess) {
             g_create_error = std::string("rt_create: ") + hipGetErrorString(e);
             ctx->devs.push_back(d);
             rt_destroy(ctx);
@@ -438,8 +450,9 @@ int rt_render(rt_ctx* ctx, const rt_render_params* p) {
     if (!ctx->uploaded) return ctx->fail(RT_ERR_NOT_UPLOADED, "rt_render: no scene uploaded");
     if (p->width == 0 || p->height == 0 || p->width > 65535u * 8u || p->height > 65535u * 8u)
         return ctx->fail(RT_ERR_BAD_ARG, "rt_render: bad resolution %ux%u", p->width, p->height);
-    if (p->mode != RT_MODE_LEGACY && p->mode != RT_MODE_WAVEFRONT)
-        return ctx->fail(RT_ERR_BAD_ARG, "rt_render: mode %u not supported", p->mode);
+    if (p->mode > RT_MODE_EXTENDED) return ctx->fail(RT_ERR_BAD_ARG, "rt_render: mode %u not supported", p->mode);
+    if (p->mode == RT_MODE_EXTENDED && (p->spp == 0 || p->spp > 65536u))
+        return ctx->fail(RT_ERR_BAD_ARG, "rt_render: spp %u out of range", p->spp);
     uint32_t world = p->tile_world ? p->tile_world : 1, rank = p->tile_rank;
     if (rank >= world) return ctx->fail(RT_ERR_BAD_ARG, "rt_render: tile_rank %u >= tile_world %u", rank, world);
     DevFrame fr{};
@@ -452,8 +465,9 @@ int rt_render(rt_ctx* ctx, const rt_render_params* p) {
     fr.mode = p->mode;
     fr.channel_mask = 7u;
     fr.cur_bounce = 0; // the bounce-0 pass of src/compute.rs:413-479 (later passes redraw the same pixels)
-    fr.max_bounce = p->max_bounces & 0xFF;
-    fr.spp = 1;
+    fr.max_bounce = p->mode == RT_MODE_EXTENDED ? p->max_bounces : (p->max_bounces & 0xFF);
+    fr.spp = p->mode == RT_MODE_EXTENDED ? p->spp : 1;
+    fr.flags = p->flags;
     fr.frame_seed = p->frame_seed;
     fr.cam = make_camera(p->camera, (float)p->width, (float)p->height, p->mode != RT_MODE_LEGACY);
     int rc = run_frame(ctx, fr, (p->flags & RT_FLAG_COUNTERS) != 0, world, rank, false);

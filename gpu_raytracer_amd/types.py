@@ -60,7 +60,8 @@ RENDER_PARAMS = np.dtype([
     ("flags", u32),
 ])
 STATS = np.dtype([
-    ("rays", np.uint64), ("primary_rays", np.uint64), ("pixels", np.uint64),
+    ("rays", np.uint64), ("primary_rays", np.uint64), ("continuation_rays", np.uint64), ("shadow_rays", np.uint64),
+    ("pixels", np.uint64),
     ("node_visits", np.uint64), ("tri_tests", np.uint64),
     ("kernel_ms", np.float64), ("wall_ms", np.float64),
     ("node_bytes", np.uint64), ("tri_bytes", np.uint64), ("scene_bytes", np.uint64),

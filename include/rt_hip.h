@@ -50,7 +50,9 @@ extern "C" {
                                 no reference implementation exists: see DESIGN.md "extended mode"      */
 
 /* rt_render_params.flags */
-#define RT_FLAG_COUNTERS 1u /* run the counting variant of the kernel: fills node_visits / tri_tests    */
+#define RT_FLAG_COUNTERS 1u   /* run the counting variant of the kernel: fills node_visits / tri_tests  */
+#define RT_FLAG_NO_SHADOWS 2u /* extended mode only: lights are not gated by shadow rays (as in the     */
+                              /* reference, which never traces them)                                    */
 
 typedef struct rt_ctx rt_ctx;
 
@@ -71,6 +73,8 @@ typedef struct rt_render_params {
 typedef struct rt_stats {
     uint64_t rays;         /* ray segments traced by the last render/dispatch (primary + continuation + shadow) */
     uint64_t primary_rays; /* camera segments among them                                             */
+    uint64_t continuation_rays; /* bounce segments (extended mode)                                   */
+    uint64_t shadow_rays;  /* shadow segments (extended mode)                                        */
     uint64_t pixels;       /* pixels written                                                          */
     uint64_t node_visits;  /* BVH nodes fetched   (only with RT_FLAG_COUNTERS, else 0)                */
     uint64_t tri_tests;    /* triangle records fetched and tested (only with RT_FLAG_COUNTERS)        */

@@ -154,3 +154,21 @@ def render_frame(packed, width, height, camera=None, mode=0, cur_bounce=0, max_b
         comb[..., 0], comb[..., 1], comb[..., 2], comb[..., 3] = chans[0][..., 0], chans[1][..., 1], chans[2][..., 2], 255
         out["combined"] = comb
     return out
+
+
+EXT_NO_SHADOWS = 2
+
+
+def render_extended(packed, width, height, spp, max_bounces, camera=None, frame_seed=0, flags=0, threads=None):
+    """Extended mode (the build's own path tracer, CPU statement).  Returns dict(rgb, segments, counters)."""
+    threads = threads or os.cpu_count() or 1
+    pc = np.ascontiguousarray(packed.push_constants(width, height, camera, 0, 1, 0, max_bounces & 0xFF, frame_seed))
+    rgb = np.zeros((height, width, 3), np.float32)
+    seg = (C.c_uint64 * 4)()
+    c = Counters()
+    rc = lib().oracle_render_extended(C.byref(packed.bindings), _ptr(pc), C.c_uint32(spp), C.c_uint32(max_bounces),
+                                      C.c_uint32(flags), C.c_int(threads), _ptr(rgb), seg, C.byref(c))
+    if rc != 0:
+        raise RuntimeError(f"oracle_render_extended failed: {rc}")
+    return {"rgb": rgb, "counters": c.as_dict(),
+            "segments": {"camera": int(seg[0]), "continuation": int(seg[1]), "shadow": int(seg[2]), "roulette": int(seg[3])}}

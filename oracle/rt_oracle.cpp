@@ -585,6 +585,237 @@ Kernel make_kernel(const oracle_bindings* b, const rt_push_constants* pc, Counte
     return k;
 }
 
+
+// =====================================================================================
+// Extended mode (RT_MODE_EXTENDED) — the build's own path tracer, stated on the CPU.
+// No reference implementation exists; the pieces it is built from are the reference's:
+// SimpleRng (shader/src/wavefront.rs:46-72), the pixel seed (shader/src/lib.rs:103-105),
+// generate_camera_ray (wavefront.rs:75-112), find_closest_intersection, the lighting /
+// BRDF of lighting.rs + material.rs, WavefrontRay's ray types and epsilon
+// (shared/src/lib.rs:833-956) and apply_russian_roulette (shared/src/lib.rs:969-978).
+// =====================================================================================
+struct SimpleRng { // wavefront.rs:46-72
+    uint32_t seed;
+    uint32_t next_u32() {
+        seed = seed * 1664525u + 1013904223u;
+        return seed;
+    }
+    float next_f32() { return (float)(next_u32() >> 8) / 16777216.0f; }
+};
+
+// pixel_seed of lib.rs:103-105, sample index mixed in, scrambled once so neighbouring
+// pixels / samples do not start on correlated LCG states.
+inline SimpleRng rng_for(uint32_t pixel_seed, uint32_t sample) {
+    uint32_t h = pixel_seed + sample * 0x9E3779B9u;
+    h ^= h >> 16;
+    h *= 0x7FEB352Du;
+    h ^= h >> 15;
+    h *= 0x846CA68Bu;
+    h ^= h >> 16;
+    return SimpleRng{h};
+}
+
+// sin/cos of 2*pi*u, u in [0,1), as explicit fmaf polynomials so the CPU and the GPU produce
+// the same bits (libm and the device math library do not agree on sinf/cosf).
+inline void sincos_2pi(float u, float* s_out, float* c_out) {
+    float f4 = u * 4.0f;
+    float qf = floorf(f4);
+    int q = (int)qf;
+    float x = (f4 - qf) * 1.57079632679489661923f;
+    float x2 = x * x;
+    float sp = fmaf(x2, -2.50521083854417187751e-8f, 2.75573192239858906526e-6f);
+    sp = fmaf(x2, sp, -1.98412698412698412698e-4f);
+    sp = fmaf(x2, sp, 8.33333333333333333333e-3f);
+    sp = fmaf(x2, sp, -1.66666666666666666667e-1f);
+    sp = fmaf(x2, sp, 1.0f);
+    float sn = x * sp;
+    float cp = fmaf(x2, 2.08767569878680989792e-9f, -2.75573192239858906526e-7f);
+    cp = fmaf(x2, cp, 2.48015873015873015873e-5f);
+    cp = fmaf(x2, cp, -1.38888888888888888889e-3f);
+    cp = fmaf(x2, cp, 4.16666666666666666667e-2f);
+    cp = fmaf(x2, cp, -0.5f);
+    float cs = fmaf(x2, cp, 1.0f);
+    switch (q & 3) {
+        case 0: *s_out = sn; *c_out = cs; break;
+        case 1: *s_out = cs; *c_out = -sn; break;
+        case 2: *s_out = -sn; *c_out = -cs; break;
+        default: *s_out = -cs; *c_out = sn; break;
+    }
+}
+
+// uniform direction on the unit sphere from two uniforms
+inline V3 unit_vector(float u1, float u2) {
+    float z = 1.0f - 2.0f * u1;
+    float r = sqrtf(fmaxf(0.0f, 1.0f - z * z));
+    float sn, cs;
+    sincos_2pi(u2, &sn, &cs);
+    return v3(r * cs, r * sn, z);
+}
+
+struct ExtCounts {
+    uint64_t camera = 0, continuation = 0, shadow = 0, roulette = 0;
+};
+
+#define EXT_EPS 0.001f /* WavefrontRay::t_min (shared/src/lib.rs:854), used as the origin offset */
+
+struct ExtKernel {
+    Kernel k; // pc: mode 1 push constants of the frame
+    uint32_t max_bounces, flags;
+
+    // Direct lighting at a vertex: the reference's calculate_lighting (lighting.rs:20-47) with every
+    // light's contribution gated by a shadow ray (unless ORACLE_EXT_NO_SHADOWS).  `ambient` adds the
+    // reference's 0.1 * albedo term (only at the terminal vertex, where no indirect light follows).
+    V3 direct(const Intersection& is, const Kernel::Mat& m, bool ambient, ExtCounts& ec) const {
+        V3 total = v3(0, 0, 0);
+        if (ambient) total = total + m.albedo * 0.1f;
+        for (uint32_t li = 0; li < k.sa.light_count(); li++) {
+            V3 contrib = k.light_contribution(is, m, li);
+            if (!(contrib.x != 0.0f || contrib.y != 0.0f || contrib.z != 0.0f)) {
+                total = total + contrib;
+                continue;
+            }
+            if (!(flags & ORACLE_EXT_NO_SHADOWS)) {
+                uint32_t ltype = k.sa.light_type(li);
+                V3 dir;
+                float tmax;
+                if (ltype == 0) {
+                    dir = -normalize(k.sa.light_direction(li));
+                    tmax = 3.402823466e+38f;
+                } else {
+                    V3 to_light = k.sa.light_position(li) - is.point;
+                    tmax = length(to_light);
+                    dir = normalize(to_light);
+                }
+                Ray sr{is.point + is.normal * EXT_EPS, dir};
+                ec.shadow++;
+                IntersectionResult occ = k.find_closest(sr);
+                if (occ.hit && occ.is.t < tmax) continue; // occluded
+            }
+            total = total + contrib;
+        }
+        return total + m.emission;
+    }
+
+    V3 trace_path(uint32_t px, uint32_t py, uint32_t sample, uint32_t spp, ExtCounts& ec) const {
+        const rt_push_constants* pc = k.pc;
+        uint32_t width = f32_as_u32(pc->resolution[0]);
+        SimpleRng rng = rng_for(pc->frame_seed + px + py * width, sample);
+        float jx = 0.5f, jy = 0.5f;
+        if (spp > 1) {
+            jx = rng.next_f32();
+            jy = rng.next_f32();
+        }
+        // generate_camera_ray (wavefront.rs:75-112) through the jittered position
+        Ray ray;
+        {
+            float u = ((float)px + jx) / pc->resolution[0];
+            float v = ((float)py + jy) / pc->resolution[1];
+            float aspect = pc->resolution[0] / pc->resolution[1];
+            float fov_scale = tanf(pc->camera.fov * 0.5f * 3.14159265358979323846f / 180.0f);
+            float cx = (u * 2.0f - 1.0f) * aspect * fov_scale;
+            float cy = (1.0f - v * 2.0f) * fov_scale;
+            V3 fwd = v3(pc->camera.direction[0], pc->camera.direction[1], pc->camera.direction[2]);
+            V3 up = v3(pc->camera.up[0], pc->camera.up[1], pc->camera.up[2]);
+            V3 right = cross(fwd, up);
+            V3 true_up = cross(right, fwd);
+            ray.origin = v3(pc->camera.position[0], pc->camera.position[1], pc->camera.position[2]);
+            ray.direction = normalize(fwd + right * cx + true_up * cy);
+        }
+        V3 radiance = v3(0, 0, 0);
+        V3 throughput = v3(1.0f, 1.0f, 1.0f); // WavefrontRay::camera_ray, shared/src/lib.rs:873
+        uint32_t channel = 3;                 // hero wavelength channel not chosen yet
+        for (uint32_t depth = 0;; depth++) {
+            if (depth == 0) ec.camera++; else ec.continuation++;
+            IntersectionResult hit = k.find_closest(ray);
+            if (!hit.hit) { // process_wavefront_ray, wavefront.rs:146-151
+                radiance = radiance + v3(0.1f, 0.2f, 0.3f) * throughput;
+                break;
+            }
+            const Intersection& is = hit.is;
+            if ((uint64_t)is.material_id >= k.b->materials_len) { // magenta, wavefront.rs:177-179
+                radiance = radiance + v3(1.0f, 0.0f, 1.0f) * throughput;
+                break;
+            }
+            Kernel::Mat m = k.material(is.material_id);
+            float roughness = f16_to_f32((uint16_t)(k.b->materials[is.material_id].metallic_roughness_f16 >> 16));
+            float tf = fminf(fmaxf(m.transmission, 0.0f), 1.0f);
+            bool terminal = depth >= max_bounces;
+            V3 lighting = direct(is, m, terminal, ec);
+            if (terminal) {
+                // the reference's calculate_shading (lib.rs:300-338), all three channel passes at once
+                V3 out = lighting;
+                if (tf > 0.0f) {
+                    float dr = (Kernel::ior_for_channel(m, 0) - 1.0f) / (m.ior - 1.0f);
+                    float dg = (Kernel::ior_for_channel(m, 1) - 1.0f) / (m.ior - 1.0f);
+                    float db = (Kernel::ior_for_channel(m, 2) - 1.0f) / (m.ior - 1.0f);
+                    float keep = 1.0f - tf;
+                    out = v3(lighting.x * keep + (0.2f * dr) * tf, lighting.y * keep + (0.2f * dg) * tf,
+                             lighting.z * keep + (0.3f * db) * tf);
+                }
+                radiance = radiance + out * throughput;
+                break;
+            }
+            // the reflective share of this vertex
+            radiance = radiance + (lighting * (1.0f - tf)) * throughput;
+
+            // --- continuation (what generate_continuation_rays, wavefront.rs:340-355, only sketches) ---
+            V3 d = ray.direction;
+            bool front = dot(is.normal, d) < 0.0f;
+            V3 nf = front ? is.normal : -is.normal;
+            bool transmit = false;
+            if (tf > 0.0f) transmit = rng.next_f32() < tf;
+            V3 ndir, norigin;
+            if (transmit) { // ray_type 2
+                if (channel == 3) {
+                    uint32_t c = (uint32_t)(rng.next_f32() * 3.0f);
+                    channel = c < 2 ? c : 2;
+                    throughput = v3(channel == 0 ? throughput.x * 3.0f : 0.0f, channel == 1 ? throughput.y * 3.0f : 0.0f,
+                                    channel == 2 ? throughput.z * 3.0f : 0.0f);
+                }
+                float ior_c = Kernel::ior_for_channel(m, channel);
+                float eta = front ? (1.0f / ior_c) : ior_c;
+                float cos_i = -dot(nf, d);
+                float sin2_t = eta * eta * (1.0f - cos_i * cos_i);
+                if (sin2_t > 1.0f) { // total internal reflection
+                    ndir = d - nf * (2.0f * dot(d, nf));
+                    norigin = is.point + nf * EXT_EPS;
+                } else {
+                    float cos_t = sqrtf(1.0f - sin2_t);
+                    ndir = d * eta + nf * (eta * cos_i - cos_t);
+                    norigin = is.point - nf * EXT_EPS;
+                }
+                ndir = normalize(ndir);
+                throughput = throughput * m.albedo;
+            } else if (m.metallic > 0.5f) { // ray_type 1, rough mirror
+                float u1 = rng.next_f32(), u2 = rng.next_f32();
+                V3 r = d - nf * (2.0f * dot(d, nf));
+                ndir = normalize(r + unit_vector(u1, u2) * roughness);
+                if (!(dot(ndir, nf) > 0.0f)) break; // scattered into the surface: absorbed
+                norigin = is.point + nf * EXT_EPS;
+                throughput = throughput * m.albedo;
+            } else { // ray_type 1, cosine-weighted diffuse
+                float u1 = rng.next_f32(), u2 = rng.next_f32();
+                V3 w = nf + unit_vector(u1, u2);
+                if (dot(w, w) < 1e-12f) w = nf;
+                ndir = normalize(w);
+                norigin = is.point + nf * EXT_EPS;
+                throughput = throughput * m.albedo;
+            }
+            // apply_russian_roulette (shared/src/lib.rs:969-978) from the third vertex on
+            if (depth >= 2) {
+                float p = fminf(fmaxf(fmaxf(fmaxf(throughput.x, throughput.y), throughput.z), 0.05f), 1.0f);
+                if (rng.next_f32() > p) {
+                    ec.roulette++;
+                    break;
+                }
+                throughput = v3(throughput.x / p, throughput.y / p, throughput.z / p);
+            }
+            ray = Ray{norigin, ndir};
+        }
+        return radiance;
+    }
+};
+
 } // namespace
 
 extern "C" {
@@ -688,8 +919,53 @@ int oracle_render_frame(const oracle_bindings* b, const rt_push_constants* base_
     return 0;
 }
 
-int oracle_render_extended(const oracle_bindings*, const rt_push_constants*, uint32_t, uint32_t, int, float*, oracle_counters*) {
-    return -2; // extended mode not specified yet
+int oracle_render_extended(const oracle_bindings* b, const rt_push_constants* base_pc, uint32_t spp, uint32_t max_bounces,
+                           uint32_t flags, int threads, float* rgb32f, uint64_t* segments, oracle_counters* counters) {
+    if (!b || !base_pc || !rgb32f || spp == 0) return -1;
+    uint32_t width = f32_as_u32(base_pc->resolution[0]);
+    uint32_t height = f32_as_u32(base_pc->resolution[1]);
+    if (width == 0 || height == 0) return -1;
+    if (threads < 1) threads = 1;
+    rt_push_constants pc = *base_pc;
+    pc.packed_flags = (base_pc->packed_flags & 0x00FFFFFFu) | (1u << 24);
+    std::atomic<uint32_t> next(0);
+    std::vector<Counters> per_thread((size_t)threads);
+    std::vector<ExtCounts> per_thread_ec((size_t)threads);
+    auto worker = [&](int tid) {
+        ExtKernel ek;
+        ek.k = make_kernel(b, &pc, &per_thread[(size_t)tid]);
+        ek.max_bounces = max_bounces;
+        ek.flags = flags;
+        ExtCounts& ec = per_thread_ec[(size_t)tid];
+        for (;;) {
+            uint32_t row = next.fetch_add(1);
+            if (row >= height) break;
+            for (uint32_t x = 0; x < width; x++) {
+                V3 sum = v3(0, 0, 0);
+                for (uint32_t s = 0; s < spp; s++) sum = sum + ek.trace_path(x, row, s, spp, ec);
+                float n = (float)spp;
+                size_t pix = (size_t)row * width + x;
+                rgb32f[pix * 3 + 0] = sum.x / n;
+                rgb32f[pix * 3 + 1] = sum.y / n;
+                rgb32f[pix * 3 + 2] = sum.z / n;
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; t++) pool.emplace_back(worker, t);
+    worker(0);
+    for (auto& t : pool) t.join();
+    for (auto& c : per_thread) c.add_to(counters);
+    if (segments) {
+        segments[0] = segments[1] = segments[2] = segments[3] = 0;
+        for (auto& e : per_thread_ec) {
+            segments[0] += e.camera;
+            segments[1] += e.continuation;
+            segments[2] += e.shadow;
+            segments[3] += e.roulette;
+        }
+    }
+    return 0;
 }
 
 } // extern "C"

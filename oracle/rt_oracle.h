@@ -70,12 +70,18 @@ int oracle_render_frame(const oracle_bindings* b, const rt_push_constants* base_
                         float* rgb32f, uint32_t* prim_ids, float* ts,
                         oracle_counters* counters);
 
-/* Extended mode (RT_MODE_EXTENDED of rt_hip.h): the CPU statement of the build's own
- * path tracer.  No reference implementation exists; this is the specification
- * the HIP kernel is checked against, not a restatement. */
+/* Extended mode (RT_MODE_EXTENDED of rt_hip.h): the CPU statement of the build's own path tracer
+ * (jittered samples, shadow rays, real bounces) built on the reference's declared-but-stub
+ * wavefront API.  NO reference implementation exists (generate_continuation_rays is a stub,
+ * shader/src/wavefront.rs:340-355), so this is the SPECIFICATION the HIP kernel is checked
+ * against, not a restatement: parity for this mode is "unpinned".  It is anchored to the pinned
+ * part by construction: with spp = 1, max_bounces = 0 and ORACLE_EXT_NO_SHADOWS it reproduces
+ * mode 1 bit for bit (tests/test_oracle_extended.py).  Full rules in DESIGN.md "Extended mode".
+ *   segments[4]: camera, continuation, shadow segments traced, and paths ended by russian roulette */
+#define ORACLE_EXT_NO_SHADOWS 2u /* same bit as RT_FLAG_NO_SHADOWS */
 int oracle_render_extended(const oracle_bindings* b, const rt_push_constants* base_pc,
-                           uint32_t spp, uint32_t max_bounces, int threads,
-                           float* rgb32f, oracle_counters* counters);
+                           uint32_t spp, uint32_t max_bounces, uint32_t flags, int threads,
+                           float* rgb32f, uint64_t* segments, oracle_counters* counters);
 
 /* Restatement of BvhBuilder::build (src/bvh.rs:104-122): empty scene -> one empty
  * leaf (:105-114); > 100,000 triangles -> chunked mesh-order leaves + bottom-up

@@ -42,3 +42,24 @@ with api.Context() as ctx:
         print("sponza 1080p kernel_ms", st["kernel_ms"], "Mrays/s", 1920*1080/st["kernel_ms"]/1e3, flush=True)
     st = ctx.render(1920, 1080, sp.camera, counters=True)
     print("counters", st, flush=True)
+
+print("---- extended mode ----", flush=True)
+def cmp_ext(name, scene, w, h, spp, b, use_bvh=False, **kw):
+    ref = oracle.render_extended(oracle.PackedScene(scene, use_bvh=use_bvh), w, h, spp, b, **kw)
+    with api.Context() as ctx:
+        ctx.upload_scene(scene)
+        st = ctx.render(w, h, scene.camera, mode=2, spp=spp, max_bounces=b, frame_seed=kw.get("frame_seed", 0))
+        rgb = ctx.read_rgb32f()
+    d = np.abs(rgb - ref["rgb"]).max(-1)
+    print(f"{name:14s} {w}x{h} {spp}spp {b}b notexact={(rgb.view(np.uint32)!=ref['rgb'].view(np.uint32)).any(-1).sum()} max|d|={d.max():.3g} out={(d>2e-3).mean():.2e} gpu segs=({st['primary_rays']},{st['continuation_rays']},{st['shadow_rays']}) cpu={ref['segments']} ms={st['kernel_ms']:.3f}", flush=True)
+cmp_ext("default", scenes.default_scene(), 96, 64, 8, 4)
+cmp_ext("cornell12", scenes.cornell12(), 64, 64, 16, 4)
+cmp_ext("soup400", scenes.random_soup(400, seed=21, size=0.7, n_spheres=3, n_lights=3), 72, 48, 6, 5, frame_seed=77)
+cmp_ext("sponza", sp, 64, 36, 2, 2, use_bvh=True)
+with api.Context() as ctx:
+    ctx.upload_scene(sp)
+    for spp, b in ((1, 0), (4, 4), (16, 4), (64, 4), (64, 0)):
+        st = ctx.render(1920, 1080, sp.camera, mode=2, spp=spp, max_bounces=b)
+        print(f"sponza 1080p ext {spp}spp {b}b: kernel_ms={st['kernel_ms']:.2f} rays={st['rays']/1e6:.1f}M (cam {st['primary_rays']/1e6:.1f} cont {st['continuation_rays']/1e6:.1f} shadow {st['shadow_rays']/1e6:.1f}) Mrays/s={st['rays']/st['kernel_ms']/1e3:.0f}", flush=True)
+    st = ctx.render(1920, 1080, sp.camera, mode=2, spp=4, max_bounces=4, counters=True)
+    print("counters 4spp", st, flush=True)
