@@ -41,7 +41,8 @@ def parse_args():
     ap.add_argument("--bounces", type=int, default=4)
     ap.add_argument("--mode", default="auto", choices=["auto", "reference", "extended"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", default="960x540", help="resolution of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-sample", default=None, help="resolution of the bounded CPU-baseline sample (default 960x540 "
+                    "for the reference mode, 160x90 at <= 4 spp for the extended mode)")
     ap.add_argument("--selftest-cpu", action="store_true",
                     help="exercise only the multi-process glue (tile partition, barrier, max-reduce) on CPU/gloo; renders nothing")
     return ap.parse_args()
@@ -105,23 +106,32 @@ def available_cpus():
     return max(1, min(n, int(os.environ.get("RT_BENCH_CPU_THREADS", "16"))))
 
 
-def cpu_baseline(scene, camera, sample, mode):
-    """The oracle (CPU restatement of the reference kernel, reference-format chunked BVH, no t-culling —
-    what the reference's kernel executes per ray) timed on this host's cores on a bounded sample."""
+def cpu_baseline(scene, camera, sample, mode_name, spp, bounces):
+    """The oracle timed on this host's cores on a BOUNDED sample of the same workload.
+    reference mode: the CPU restatement of the reference kernel walking the reference-format BVH (chunked
+    mesh-order leaves, no t-culling: what the reference's kernel executes per ray).
+    extended mode: the CPU statement of the extended mode (same reference-format BVH traversal per segment)."""
     import oracle
     w, h = (int(v) for v in sample.split("x"))
     cores = available_cpus()
     packed = oracle.PackedScene(scene)
     t0 = time.perf_counter()
-    # 32x32 work items so every thread stays busy; the image does not depend on the tile size
-    r = oracle.render_frame(packed, w, h, camera=camera, mode=mode, threads=cores, want_rgba8=False, tile_size=32)
+    if mode_name == "extended":
+        sspp = min(spp, 4)
+        r = oracle.render_extended(packed, w, h, sspp, bounces, camera=camera, threads=cores)
+        rays = sum(r["segments"][k] for k in ("camera", "continuation", "shadow"))
+        what = f"{sspp} spp {bounces} bounces extended mode"
+    else:
+        # 32x32 work items so every thread stays busy; the image does not depend on the tile size
+        r = oracle.render_frame(packed, w, h, camera=camera, mode=1, threads=cores, want_rgba8=False, tile_size=32)
+        rays = r["counters"]["rays"]
+        what = "1 spp primary rays"
     dt = time.perf_counter() - t0
-    rays = r["counters"]["rays"]
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"{scene.name} {w}x{h} 1 spp primary rays, same camera, reference-format BVH "
-                      f"({len(packed.nodes)} nodes), {dt:.2f} s",
-            "nodes_per_ray": r["counters"]["node_visits"] / max(rays, 1),
-            "tris_per_ray": r["counters"]["tri_tests"] / max(rays, 1)}
+            "sample": f"{scene.name} {w}x{h} {what}, same camera, reference-format BVH ({len(packed.nodes)} nodes, no t-culling), "
+                      f"{rays} segments in {dt:.2f} s",
+            "nodes_per_ray": r["counters"]["node_visits"] / max(r["counters"]["rays"], 1),
+            "tris_per_ray": r["counters"]["tri_tests"] / max(r["counters"]["rays"], 1)}
 
 
 def load_traffic(workload):
@@ -211,7 +221,9 @@ def main():
             "config": {"workload": workload, "scene": scene.name, "triangles": scene.n_triangles,
                        "resolution": [args.width, args.height], "spp": spp, "mode": mode_name,
                        "partition": f"tiles {tile}x{tile} interleaved over {n_gpus} rank(s), scene replicated, no collective",
+                       "bounces": bounces if mode_name == "extended" else 0,
                        "rays_per_step": total_rays / args.steps,
+                       "segments_rank0": {"camera": stc["primary_rays"], "continuation": stc["continuation_rays"], "shadow": stc["shadow_rays"]},
                        "kernel_mrays_per_s_rank0": stc["rays"] / avg_kernel_ms / 1e3},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(f"{scene.name}_{args.width}x{args.height}_{mode_name}"),
@@ -222,7 +234,8 @@ def main():
                                  "the 23 MB scene is cache resident, so this exceeds what HBM itself moves (see traffic)"},
         }
         if n_gpus == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene, scene.camera, args.cpu_sample, 1)
+            sample = args.cpu_sample or ("160x90" if mode_name == "extended" else "960x540")
+            out["cpu_baseline"] = cpu_baseline(scene, scene.camera, sample, mode_name, spp, bounces)
         print(json.dumps(out), flush=True)
     ctx.close()
     if dist is not None:

@@ -395,7 +395,7 @@ __global__ __launch_bounds__(WAVE) void k_render_reference(DevScene sc, DevFrame
 // the reference's declared-but-stub wavefront API (SimpleRng wavefront.rs:46-72, pixel seed
 // lib.rs:103-105, generate_camera_ray wavefront.rs:75-112, WavefrontRay types and epsilon
 // shared/src/lib.rs:833-956, apply_russian_roulette shared/src/lib.rs:969-978).  The rules are
-// stated in DESIGN.md "Extended mode" and, executable, in oracle/rt_oracle.cpp (ExtKernel);
+// stated in DESIGN.md "Extended mode" (the test suite holds an executable CPU statement of them);
 // this is the same arithmetic in the same order.
 // ====================================================================================
 struct SimpleRng {

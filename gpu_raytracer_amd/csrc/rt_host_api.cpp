@@ -1,0 +1,126 @@
+// rt_host_api.cpp — C wrappers (include/rt_host.h) around the C++ host mirror raytracer_host.hpp.
+#include "../../include/rt_host.h"
+
+#include "host/raytracer_host.hpp"
+
+using namespace raytracer;
+
+extern "C" {
+
+void rt_host_material_new(rt_material* out, const float albedo[3], float metallic, float roughness, const float emission[3], float ior,
+                          float transmission) {
+    *out = material::new_(albedo, metallic, roughness, emission, ior, transmission);
+}
+
+void rt_host_light_new(rt_light* out, uint32_t light_type, const float position[3], const float direction[3], const float color[3],
+                       float intensity, float range, float inner_cone, float outer_cone) {
+    if (light_type == 0) *out = light::directional(direction, color, intensity);
+    else if (light_type == 1) *out = light::point(position, color, intensity, range);
+    else *out = light::spot(position, direction, color, intensity, range, inner_cone, outer_cone);
+}
+
+void rt_host_push_constants_new(rt_push_constants* out, const float resolution[2], const rt_camera* camera, uint32_t triangle_count,
+                                uint32_t material_count, const uint32_t tile_offset[2], const uint32_t tile_size[2],
+                                const uint32_t total_tiles[2], uint32_t triangles_per_buffer, const rt_scene_metadata_offsets* offsets,
+                                uint32_t color_channel, uint32_t wavefront_mode, uint32_t current_bounce, uint32_t max_bounce,
+                                uint32_t frame_seed) {
+    if (wavefront_mode == 0)
+        *out = push_constants::new_(resolution, *camera, triangle_count, material_count, tile_offset, tile_size, total_tiles,
+                                    triangles_per_buffer, *offsets, color_channel);
+    else
+        *out = push_constants::new_wavefront(resolution, *camera, triangle_count, material_count, tile_offset, tile_size, total_tiles,
+                                             triangles_per_buffer, *offsets, color_channel, current_bounce, max_bounce, frame_seed);
+}
+
+void rt_host_tile_count(uint32_t width, uint32_t height, uint32_t tile_size, uint32_t* tiles_x, uint32_t* tiles_y) {
+    TileHelper::calculate_tile_count(width, height, tile_size, tiles_x, tiles_y);
+}
+
+uint32_t rt_host_tiles_per_frame(uint32_t total_tiles) { return TileHelper::calculate_tiles_per_frame(total_tiles); }
+
+int rt_host_default_scene(rt_sphere* spheres, uint32_t* n_spheres, rt_triangle* triangles, uint32_t* n_triangles, rt_vertex* vertices,
+                          uint32_t* n_vertices, rt_material* materials, uint32_t* n_materials, rt_light* lights, uint32_t* n_lights,
+                          rt_camera* cam) {
+    std::vector<Sphere> s;
+    std::vector<Triangle> t;
+    std::vector<Vertex> v;
+    std::vector<Material> m;
+    std::vector<Light> l;
+    SceneBuilder::build_default_scene(s, t, v, m, l);
+    if (*n_spheres < s.size() || *n_triangles < t.size() || *n_vertices < v.size() || *n_materials < m.size() || *n_lights < l.size()) return -1;
+    std::copy(s.begin(), s.end(), spheres);
+    std::copy(t.begin(), t.end(), triangles);
+    std::copy(v.begin(), v.end(), vertices);
+    std::copy(m.begin(), m.end(), materials);
+    std::copy(l.begin(), l.end(), lights);
+    *n_spheres = (uint32_t)s.size();
+    *n_triangles = (uint32_t)t.size();
+    *n_vertices = (uint32_t)v.size();
+    *n_materials = (uint32_t)m.size();
+    *n_lights = (uint32_t)l.size();
+    if (cam) *cam = camera::new_();
+    return 0;
+}
+
+int rt_host_bvh_build(const rt_triangle* triangles, uint32_t n_triangles, const rt_vertex* vertices, uint32_t n_vertices, rt_bvh_node* nodes,
+                      uint32_t* n_nodes, uint32_t* triangle_indices, uint32_t* n_indices) {
+    if (!n_nodes || !n_indices) return RT_ERR_BAD_ARG;
+    for (uint32_t i = 0; i < n_triangles; i++)
+        if (triangles[i].v0_index >= n_vertices || triangles[i].v1_index >= n_vertices || triangles[i].v2_index >= n_vertices) return RT_ERR_BAD_ARG;
+    std::vector<Triangle> t(triangles, triangles + n_triangles);
+    std::vector<Vertex> v(vertices, vertices + n_vertices);
+    BvhResult r = BvhBuilder::build(t, v);
+    if (nodes) {
+        if (*n_nodes < r.nodes.size() || *n_indices < r.triangle_indices.size()) return RT_ERR_BAD_ARG;
+        std::copy(r.nodes.begin(), r.nodes.end(), nodes);
+        if (triangle_indices) std::copy(r.triangle_indices.begin(), r.triangle_indices.end(), triangle_indices);
+    }
+    *n_nodes = (uint32_t)r.nodes.size();
+    *n_indices = (uint32_t)r.triangle_indices.size();
+    return RT_OK;
+}
+
+int rt_host_pack_scene_metadata(const rt_sphere* spheres, uint32_t n_spheres, const rt_light* lights, uint32_t n_lights, const rt_bvh_node* nodes,
+                                uint32_t n_nodes, const uint32_t* tri_indices, uint32_t n_indices, const rt_vertex* vertices, uint32_t n_vertices,
+                                uint32_t* combined, size_t capacity_words, rt_scene_metadata_offsets* offsets) {
+    std::vector<uint32_t> buf;
+    SceneMetadataOffsets off = BufferManager::pack_scene_metadata(
+        std::vector<Sphere>(spheres, spheres + n_spheres), std::vector<Light>(lights, lights + n_lights), std::vector<BvhNode>(nodes, nodes + n_nodes),
+        std::vector<uint32_t>(tri_indices, tri_indices + n_indices), std::vector<Vertex>(vertices, vertices + n_vertices), buf);
+    if (buf.size() > capacity_words) return RT_ERR_BAD_ARG;
+    if (!buf.empty()) std::memcpy(combined, buf.data(), buf.size() * 4);
+    if (offsets) *offsets = off;
+    return RT_OK;
+}
+
+int rt_host_render_progressive(rt_ctx* ctx, const rt_sphere* spheres, uint32_t n_spheres, const rt_light* lights, uint32_t n_lights,
+                               const rt_vertex* vertices, uint32_t n_vertices, const rt_triangle* triangles, uint32_t n_triangles,
+                               const rt_material* materials, uint32_t n_materials, const rt_camera* cam, uint32_t width, uint32_t height,
+                               uint32_t* n_dispatches, uint32_t* n_calls) {
+    if (!ctx || !cam || width == 0 || height == 0) return RT_ERR_BAD_ARG;
+    SceneState scene;
+    scene.spheres.assign(spheres, spheres + n_spheres);
+    scene.lights.assign(lights, lights + n_lights);
+    scene.vertices.assign(vertices, vertices + n_vertices);
+    scene.triangles.assign(triangles, triangles + n_triangles);
+    scene.materials.assign(materials, materials + n_materials);
+    scene.camera = *cam;
+    for (const auto& t : scene.triangles)
+        if (t.v0_index >= n_vertices || t.v1_index >= n_vertices || t.v2_index >= n_vertices) return RT_ERR_BAD_ARG;
+    scene.rebuild_bvh();
+    BufferManager buffers;
+    ProgressiveState progressive;
+    progressive.resize(width, height);
+    uint32_t calls = 0;
+    bool done = false;
+    while (!done) {
+        int rc = ComputeRenderer::run_compute(ctx, buffers, scene, progressive, &done);
+        if (rc != RT_OK) return rc;
+        if (++calls > 1000000u) return RT_ERR_INTERNAL;
+    }
+    if (n_dispatches) *n_dispatches = progressive.tiles_x * progressive.tiles_y * 3;
+    if (n_calls) *n_calls = calls;
+    return RT_OK;
+}
+
+} // extern "C"

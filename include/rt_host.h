@@ -1,0 +1,60 @@
+/*
+ * rt_host.h — C entry points onto the C++ host mirror (gpu_raytracer_amd/csrc/host/raytracer_host.hpp),
+ * so that non-C++ hosts and the Python tests can reach the reference-named host functions.
+ * Each function names the reference function it mirrors.  These are conveniences above the boundary;
+ * the drop-in boundary itself is rt_hip.h.
+ */
+#ifndef RT_HOST_H
+#define RT_HOST_H
+
+#include "rt_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Material::new (shared/src/lib.rs:255-291): f16 packing metallic lo16 | roughness hi16, ior lo16 | transmission hi16 */
+void rt_host_material_new(rt_material* out, const float albedo[3], float metallic, float roughness, const float emission[3],
+                          float ior, float transmission);
+/* Light::directional / point / spot (shared/src/lib.rs:497-586); light_type selects which */
+void rt_host_light_new(rt_light* out, uint32_t light_type, const float position[3], const float direction[3], const float color[3],
+                       float intensity, float range, float inner_cone, float outer_cone);
+/* PushConstants::new (mode 0) / new_wavefront (mode != 0) (shared/src/lib.rs:1076-1134) */
+void rt_host_push_constants_new(rt_push_constants* out, const float resolution[2], const rt_camera* camera, uint32_t triangle_count,
+                                uint32_t material_count, const uint32_t tile_offset[2], const uint32_t tile_size[2],
+                                const uint32_t total_tiles[2], uint32_t triangles_per_buffer, const rt_scene_metadata_offsets* offsets,
+                                uint32_t color_channel, uint32_t wavefront_mode, uint32_t current_bounce, uint32_t max_bounce,
+                                uint32_t frame_seed);
+/* TileHelper::calculate_tile_count / calculate_tiles_per_frame (shared/src/lib.rs:1187-1203) */
+void rt_host_tile_count(uint32_t width, uint32_t height, uint32_t tile_size, uint32_t* tiles_x, uint32_t* tiles_y);
+uint32_t rt_host_tiles_per_frame(uint32_t total_tiles);
+
+/* SceneBuilder::build_default_scene (shared/src/lib.rs:1242-1286) + Camera::new.  Arrays must hold
+ * 6 spheres, 2 triangles, 6 vertices, 4 materials, 1 light; returns 0, or -1 if a capacity is too small. */
+int rt_host_default_scene(rt_sphere* spheres, uint32_t* n_spheres, rt_triangle* triangles, uint32_t* n_triangles, rt_vertex* vertices,
+                          uint32_t* n_vertices, rt_material* materials, uint32_t* n_materials, rt_light* lights, uint32_t* n_lights,
+                          rt_camera* camera);
+
+/* BvhBuilder::build (src/bvh.rs:104-122): reference-format BVH.  Call with nodes == NULL for the counts. */
+int rt_host_bvh_build(const rt_triangle* triangles, uint32_t n_triangles, const rt_vertex* vertices, uint32_t n_vertices,
+                      rt_bvh_node* nodes, uint32_t* n_nodes, uint32_t* triangle_indices, uint32_t* n_indices);
+
+/* BufferManager::update_scene_metadata's packing (src/buffers.rs:213-268): combined must hold
+ * 5*n_spheres + 13*n_lights + 12*n_nodes + n_indices + 3*n_vertices words. */
+int rt_host_pack_scene_metadata(const rt_sphere* spheres, uint32_t n_spheres, const rt_light* lights, uint32_t n_lights,
+                                const rt_bvh_node* nodes, uint32_t n_nodes, const uint32_t* tri_indices, uint32_t n_indices,
+                                const rt_vertex* vertices, uint32_t n_vertices, uint32_t* combined, size_t capacity_words,
+                                rt_scene_metadata_offsets* offsets);
+
+/* The reference's whole frame loop on an rt_ctx: BvhBuilder::build -> BufferManager::update_* ->
+ * ComputeRenderer::run_compute repeated until the image is complete (src/compute.rs:12-251), i.e. one
+ * rt_upload_scene_packed and tiles x 3 rt_dispatch_tile calls.  *n_dispatches receives the dispatch count. */
+int rt_host_render_progressive(rt_ctx* ctx, const rt_sphere* spheres, uint32_t n_spheres, const rt_light* lights, uint32_t n_lights,
+                               const rt_vertex* vertices, uint32_t n_vertices, const rt_triangle* triangles, uint32_t n_triangles,
+                               const rt_material* materials, uint32_t n_materials, const rt_camera* camera, uint32_t width,
+                               uint32_t height, uint32_t* n_dispatches, uint32_t* n_calls);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -37,7 +37,8 @@ def test_product_does_not_import_or_link_the_oracle(rt_api):
         for f in files:
             if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")):
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
-                assert "import oracle" not in src and "from oracle" not in src and "rt_oracle" not in src and "liboracle" not in src, f
+                assert "import oracle" not in src and "from oracle" not in src and "liboracle" not in src, f
+                assert not re.search(r'#\s*include\s*[<"][^>"]*oracle', src), f
     assert b"liboracle" not in open(rt_api.LIB_PATH, "rb").read()
 
 
