@@ -12,13 +12,14 @@ import numpy as np
 from . import types as T
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt_hip.so")
+LIB_PATH = os.environ.get("RT_HIP_LIB", os.path.join(_HERE, "librt_hip.so"))  # RT_HIP_LIB: development override (kernel variants)
 
 RT_OK = 0
 ERRORS = {-1: "RT_ERR_BAD_ARG", -2: "RT_ERR_OOM", -3: "RT_ERR_HIP", -4: "RT_ERR_NOT_UPLOADED", -5: "RT_ERR_INTERNAL"}
 MODE_LEGACY, MODE_WAVEFRONT, MODE_EXTENDED = 0, 1, 2
 FLAG_COUNTERS = 1
 FLAG_NO_SHADOWS = 2
+FLAG_KERNEL_V1 = 4
 EXTENDED_AVAILABLE = True
 
 # every symbol include/rt_hip.h declares
@@ -120,12 +121,12 @@ class Context:
 
     # -- rendering -------------------------------------------------------------------
     def render(self, width, height, camera, mode=MODE_LEGACY, spp=1, max_bounces=4, frame_seed=0, tile_size=0,
-               tile_rank=0, tile_world=1, counters=False, no_shadows=False):
+               tile_rank=0, tile_world=1, counters=False, no_shadows=False, kernel_v1=False):
         p = np.zeros((), dtype=T.RENDER_PARAMS)
         p["camera"] = camera
         p["width"], p["height"], p["spp"], p["max_bounces"], p["mode"] = width, height, spp, max_bounces, mode
         p["frame_seed"], p["tile_size"], p["tile_rank"], p["tile_world"] = frame_seed, tile_size, tile_rank, tile_world
-        p["flags"] = (FLAG_COUNTERS if counters else 0) | (FLAG_NO_SHADOWS if no_shadows else 0)
+        p["flags"] = (FLAG_COUNTERS if counters else 0) | (FLAG_NO_SHADOWS if no_shadows else 0) | (FLAG_KERNEL_V1 if kernel_v1 else 0)
         self._check(self.lib.rt_render(self._h, _p(p)))
         self.width, self.height = width, height
         return self.stats()
@@ -157,6 +158,12 @@ class Context:
         t = np.zeros((self.height, self.width), np.float32)
         self._check(self.lib.rt_read_hits(self._h, _p(prim), _p(t), C.c_size_t(prim.size)))
         return prim, t
+
+    def debug_counters(self):
+        out = (C.c_ulonglong * 8)()
+        self._check(self.lib.rt_debug_counters(self._h, out))
+        names = ("transition_passes", "transition_lanes", "node_iters", "node_lanes", "leaf_iters", "leaf_lanes", "cycles_transition", "cycles_traversal")
+        return dict(zip(names, [int(v) for v in out]))
 
     def stats(self):
         st = np.zeros((), dtype=T.STATS)

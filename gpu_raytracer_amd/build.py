@@ -24,7 +24,11 @@ def needs_build():
     return any(os.path.isfile(d) and os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True, extra=()):
+def build(force=False, verbose=True, extra=(), out=None):
+    global LIB
+    if out:
+        LIB = out
+        force = True
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -37,4 +41,10 @@ def build(force=False, verbose=True, extra=()):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, extra=[a for a in sys.argv[1:] if a.startswith("-") and a != "--force"])
+    out = None
+    args = sys.argv[1:]
+    if "--out" in args:
+        i = args.index("--out")
+        out = args[i + 1]
+        del args[i:i + 2]
+    build(force="--force" in args, extra=[a for a in args if a.startswith("-") and a != "--force"], out=out)

@@ -627,6 +627,350 @@ __global__ __launch_bounds__(WAVE) void k_render_extended(DevScene sc, DevFrame 
     }
 }
 
+
+// ====================================================================================
+// k_render_extended_sm — extended mode as a per-lane STATE MACHINE (v2).
+//
+// v1 (k_render_extended) nests the loops samples -> path vertices -> lights -> traversal, so a
+// wave runs every traversal in lockstep and lanes whose segment ends early idle until the
+// slowest lane is done (measured: ~17 % lane utilisation, profiles/r01_extended_*_v1).  Here
+// every lane carries its own path state and the wave alternates between two phases:
+//   traversal phase  - one BVH step at a time for every lane that has a segment in flight
+//                      (closest-hit and any-hit shadow segments mixed); a lane whose segment
+//                      finishes parks;
+//   transition phase - entered when no lane is traversing or RT_SM_PARK_THRESHOLD lanes are
+//                      parked (__ballot + popcount): parked lanes consume their result (shade,
+//                      next light, next bounce, next sample) and set up their next segment.
+// Per-lane arithmetic and its order are exactly those of v1 / the CPU statement; only the
+// interleaving across lanes changes, so results stay bit-identical.
+// ====================================================================================
+#ifndef RT_SM_MIN_WAVES
+#define RT_SM_MIN_WAVES 4
+#endif
+#ifndef RT_SM_PARK_THRESHOLD
+#define RT_SM_PARK_THRESHOLD 8
+#endif
+
+enum : uint32_t { ST_NEW_SAMPLE = 0, ST_CLOSEST_DONE = 1, ST_SHADOW_DONE = 2, ST_LIGHTS = 3, ST_TRAVERSING = 4, ST_DONE = 5 };
+
+template <bool COUNT>
+__global__ __launch_bounds__(WAVE, RT_SM_MIN_WAVES) void k_render_extended_sm(DevScene sc, DevFrame fr, DevTargets tg) {
+    __shared__ uint32_t s_stack[RT_DEV_STACK_DEPTH * WAVE];
+    const PixelCoord px = block_pixel(fr);
+    uint32_t* __restrict__ stack = s_stack + threadIdx.x;
+    const float4* __restrict__ nodes = reinterpret_cast<const float4*>(sc.nodes);
+    Counts cnt = {0u, 0u};
+    SegCounts seg = {0u, 0u, 0u};
+    const bool shadows = (fr.flags & 2u) == 0;
+
+    // ---- per-lane path state ----
+    uint32_t state = px.valid ? ST_NEW_SAMPLE : ST_DONE;
+    uint32_t sample = 0, depth = 0, channel = 3, li = 0, material_id = 0;
+    SimpleRng rng = {0u};
+    V3 sum = v3(0.0f, 0.0f, 0.0f), radiance = sum, throughput = sum, lighting = sum, pending = sum;
+    V3 point = sum, normal = sum, din = sum; // vertex position, geometric normal, incoming direction
+    bool terminal = false;
+    // ---- per-lane segment (traversal) state ----
+    V3 o = sum, d = sum, inv = sum;
+    Hit hit;
+    hit.t = RT_F32_MAX;
+    hit.prim = RT_PRIM_MISS;
+    hit.slot = 0;
+    uint32_t cur = 0;
+    int sp = 0;
+    bool anyhit = false;
+
+    // start a segment: spheres are tested right away (wave-uniform loop), the BVH walk is deferred to the traversal phase
+    auto begin_segment = [&](V3 so, V3 sd, float tmax, bool any) {
+        o = so;
+        d = sd;
+        inv = v3(1.0f / sd.x, 1.0f / sd.y, 1.0f / sd.z);
+        hit.t = tmax;
+        hit.prim = RT_PRIM_MISS;
+        hit.slot = 0;
+        anyhit = any;
+        test_spheres(sc, so, sd, hit);
+        sp = 0;
+        cur = sc.root_ref;
+        const bool finished = sc.n_tris == 0 || (any && hit.prim != RT_PRIM_MISS);
+        state = finished ? (any ? ST_SHADOW_DONE : ST_CLOSEST_DONE) : ST_TRAVERSING;
+    };
+
+    // diagnostics of the counting variant (wave-level, lane 0 accumulates): [8] transition passes, [9] lanes served,
+    // [10] node iterations, [11] lanes active in them, [12] leaf iterations, [13] lanes active, [14]/[15] cycles in
+    // transition / traversal phases
+    unsigned long long dg_tp = 0, dg_tl = 0, dg_ni = 0, dg_nl = 0, dg_li = 0, dg_ll = 0, dg_ct = 0, dg_cv = 0;
+    for (;;) {
+        // =========================== transition phase ===========================
+        unsigned long long t_begin = 0;
+        if (COUNT) {
+            unsigned long long need = __ballot(state != ST_TRAVERSING && state != ST_DONE);
+            if (need) {
+                dg_tp++;
+                dg_tl += __popcll(need);
+            }
+            t_begin = __builtin_readcyclecounter();
+        }
+        while (state != ST_TRAVERSING && state != ST_DONE) {
+            if (state == ST_NEW_SAMPLE) {
+                if (sample >= fr.spp) {
+                    float n = (float)fr.spp;
+                    V3 color = v3(sum.x / n, sum.y / n, sum.z / n);
+                    const size_t pix = (size_t)px.y * fr.width + px.x;
+                    if (tg.rgba32f) reinterpret_cast<float4*>(tg.rgba32f)[pix] = make_float4(color.x, color.y, color.z, 1.0f);
+                    if (tg.chan[0]) reinterpret_cast<uint32_t*>(tg.chan[0])[pix] = unorm8(color.x) | 0xFF000000u;
+                    if (tg.chan[1]) reinterpret_cast<uint32_t*>(tg.chan[1])[pix] = (unorm8(color.y) << 8) | 0xFF000000u;
+                    if (tg.chan[2]) reinterpret_cast<uint32_t*>(tg.chan[2])[pix] = (unorm8(color.z) << 16) | 0xFF000000u;
+                    state = ST_DONE;
+                    break;
+                }
+                rng = rng_for(fr.frame_seed + px.x + px.y * fr.width, sample);
+                float jx = 0.5f, jy = 0.5f;
+                if (fr.spp > 1) {
+                    jx = rng.next_f32();
+                    jy = rng.next_f32();
+                }
+                V3 co, cd;
+                camera_ray(fr.cam, (float)px.x + jx, (float)px.y + jy, true, co, cd);
+                radiance = v3(0.0f, 0.0f, 0.0f);
+                throughput = v3(1.0f, 1.0f, 1.0f);
+                channel = 3;
+                depth = 0;
+                seg.camera++;
+                begin_segment(co, cd, RT_F32_MAX, false);
+                continue;
+            }
+            bool end_sample = false;
+            if (state == ST_CLOSEST_DONE) {
+                if (hit.prim == RT_PRIM_MISS) {
+                    radiance = radiance + v3(0.1f, 0.2f, 0.3f) * throughput;
+                    end_sample = true;
+                } else {
+                    hit_geometry(sc, hit, o, d, point, normal, material_id);
+                    din = d;
+                    if (material_id >= sc.n_materials) {
+                        radiance = radiance + v3(1.0f, 0.0f, 1.0f) * throughput;
+                        end_sample = true;
+                    } else {
+                        terminal = depth >= fr.max_bounce;
+                        lighting = v3(0.0f, 0.0f, 0.0f);
+                        if (terminal) lighting = lighting + ld3(sc.materials[material_id].albedo) * 0.1f;
+                        li = 0;
+                        state = ST_LIGHTS;
+                    }
+                }
+            } else if (state == ST_SHADOW_DONE) {
+                if (hit.prim == RT_PRIM_MISS) lighting = lighting + pending;
+                li++;
+                state = ST_LIGHTS;
+            }
+            if (!end_sample && state == ST_LIGHTS) {
+                const DevMaterial m = sc.materials[material_id];
+                bool launched = false;
+                while (li < sc.n_lights) {
+                    V3 sdir;
+                    float sdist;
+                    V3 contrib = light_contribution(sc.lights[li], m, point, normal, sdir, sdist);
+                    if ((contrib.x != 0.0f || contrib.y != 0.0f || contrib.z != 0.0f) && shadows) {
+                        pending = contrib;
+                        seg.shadow++;
+                        launched = true;
+                        begin_segment(point + normal * EXT_EPS, sdir, sdist, true); // overwrites o/d: the incoming direction lives in `din`
+                        break;
+                    }
+                    lighting = lighting + contrib;
+                    li++;
+                }
+                if (launched) continue;
+                // ---- all lights done: finish the vertex ----
+                lighting = lighting + ld3(m.emission);
+                float tf = fminf(fmaxf(m.transmission, 0.0f), 1.0f);
+                if (terminal) {
+                    V3 out = lighting;
+                    if (tf > 0.0f) out = transmission_mix(m, lighting, tf);
+                    radiance = radiance + out * throughput;
+                    end_sample = true;
+                } else {
+                    radiance = radiance + (lighting * (1.0f - tf)) * throughput;
+                    bool front = dot(normal, din) < 0.0f;
+                    V3 nf = front ? normal : -normal;
+                    bool transmit = false;
+                    if (tf > 0.0f) transmit = rng.next_f32() < tf;
+                    V3 ndir, norigin;
+                    V3 albedo = ld3(m.albedo);
+                    bool absorbed = false;
+                    if (transmit) {
+                        if (channel == 3) {
+                            uint32_t c = (uint32_t)(rng.next_f32() * 3.0f);
+                            channel = c < 2 ? c : 2;
+                            throughput = v3(channel == 0 ? throughput.x * 3.0f : 0.0f, channel == 1 ? throughput.y * 3.0f : 0.0f,
+                                            channel == 2 ? throughput.z * 3.0f : 0.0f);
+                        }
+                        float offs = channel == 0 ? -0.018f : (channel == 1 ? 0.0f : 0.035f);
+                        float ior_c = m.ior + offs;
+                        float eta = front ? (1.0f / ior_c) : ior_c;
+                        float cos_i = -dot(nf, din);
+                        float sin2_t = eta * eta * (1.0f - cos_i * cos_i);
+                        if (sin2_t > 1.0f) {
+                            ndir = din - nf * (2.0f * dot(din, nf));
+                            norigin = point + nf * EXT_EPS;
+                        } else {
+                            float cos_t = sqrtf(1.0f - sin2_t);
+                            ndir = din * eta + nf * (eta * cos_i - cos_t);
+                            norigin = point - nf * EXT_EPS;
+                        }
+                        ndir = normalize(ndir);
+                        throughput = throughput * albedo;
+                    } else if (m.metallic > 0.5f) {
+                        float u1 = rng.next_f32(), u2 = rng.next_f32();
+                        V3 r = din - nf * (2.0f * dot(din, nf));
+                        ndir = normalize(r + unit_vector(u1, u2) * m.roughness);
+                        absorbed = !(dot(ndir, nf) > 0.0f);
+                        norigin = point + nf * EXT_EPS;
+                        if (!absorbed) throughput = throughput * albedo;
+                    } else {
+                        float u1 = rng.next_f32(), u2 = rng.next_f32();
+                        V3 w = nf + unit_vector(u1, u2);
+                        if (dot(w, w) < 1e-12f) w = nf;
+                        ndir = normalize(w);
+                        norigin = point + nf * EXT_EPS;
+                        throughput = throughput * albedo;
+                    }
+                    if (!absorbed && depth >= 2) {
+                        float p = fminf(fmaxf(fmaxf(fmaxf(throughput.x, throughput.y), throughput.z), 0.05f), 1.0f);
+                        if (rng.next_f32() > p) absorbed = true;
+                        else throughput = v3(throughput.x / p, throughput.y / p, throughput.z / p);
+                    }
+                    if (absorbed) {
+                        end_sample = true;
+                    } else {
+                        depth++;
+                        seg.continuation++;
+                        begin_segment(norigin, ndir, RT_F32_MAX, false);
+                    }
+                }
+            }
+            if (end_sample) {
+                sum = sum + radiance;
+                sample++;
+                state = ST_NEW_SAMPLE;
+            }
+        }
+        if (COUNT) {
+            unsigned long long t_mid = __builtin_readcyclecounter();
+            dg_ct += t_mid - t_begin;
+            t_begin = t_mid;
+        }
+        // =========================== anything left? ===========================
+        if (__ballot(state == ST_TRAVERSING) == 0ull) {
+            if (__ballot(state != ST_DONE) == 0ull) break;
+            continue;
+        }
+        // =========================== traversal phase ===========================
+        // while-while: all lanes that stand on an inner node step until none does, then the lanes that reached
+        // a leaf test its triangles.  (A speculative variant that postpones one leaf per lane and keeps
+        // descending raised lane utilisation of the node steps from 26 % to 48 % but was not faster: the
+        // kernel is bound by vector-memory instructions per segment, not by idle lanes — DESIGN.md §4.)
+        for (;;) {
+            for (;;) {
+                const bool want = state == ST_TRAVERSING && !(cur & RT_DEV_LEAF_FLAG);
+                const unsigned long long wmask = __ballot(want);
+                if (wmask == 0ull) break;
+                if (COUNT) {
+                    dg_ni++;
+                    dg_nl += __popcll(wmask);
+                }
+                if (want) {
+                    const float4* n = nodes + (size_t)cur * 4;
+                    float4 a = n[0], b = n[1], c = n[2], e = n[3];
+                    if (COUNT) cnt.nodes++;
+                    float t0x = (a.x - o.x) * inv.x, t0y = (a.y - o.y) * inv.y, t0z = (a.z - o.z) * inv.z;
+                    float t1x = (b.x - o.x) * inv.x, t1y = (b.y - o.y) * inv.y, t1z = (b.z - o.z) * inv.z;
+                    float u0x = (c.x - o.x) * inv.x, u0y = (c.y - o.y) * inv.y, u0z = (c.z - o.z) * inv.z;
+                    float u1x = (e.x - o.x) * inv.x, u1y = (e.y - o.y) * inv.y, u1z = (e.z - o.z) * inv.z;
+                    float tmin0 = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
+                    float tmax0 = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
+                    float tmin1 = fmaxf(fmaxf(fminf(u0x, u1x), fminf(u0y, u1y)), fminf(u0z, u1z));
+                    float tmax1 = fminf(fminf(fmaxf(u0x, u1x), fmaxf(u0y, u1y)), fmaxf(u0z, u1z));
+                    float limit = hit.t * 1.0000153f;
+                    bool h0 = tmax0 >= 0.0f && tmin0 <= tmax0 && tmin0 <= limit;
+                    bool h1 = tmax1 >= 0.0f && tmin1 <= tmax1 && tmin1 <= limit;
+                    uint32_t c0 = __float_as_uint(a.w), c1 = __float_as_uint(b.w);
+                    if (h0 && h1) {
+                        bool first0 = tmin0 <= tmin1;
+                        if (sp < RT_DEV_STACK_DEPTH) {
+                            stack[sp * WAVE] = first0 ? c1 : c0;
+                            sp++;
+                        }
+                        cur = first0 ? c0 : c1;
+                    } else if (h0) {
+                        cur = c0;
+                    } else if (h1) {
+                        cur = c1;
+                    } else if (sp > 0) {
+                        sp--;
+                        cur = stack[sp * WAVE];
+                    } else {
+                        state = anyhit ? ST_SHADOW_DONE : ST_CLOSEST_DONE;
+                    }
+                }
+            }
+            if (COUNT) {
+                unsigned long long lm = __ballot(state == ST_TRAVERSING);
+                if (lm) {
+                    dg_li++;
+                    dg_ll += __popcll(lm);
+                }
+            }
+            if (state == ST_TRAVERSING) { // cur is a leaf reference here
+                uint32_t start = cur & RT_DEV_LEAF_START_MASK;
+                uint32_t count = (cur >> RT_DEV_LEAF_COUNT_SHIFT) & 0xFu;
+                bool stop = false;
+                for (uint32_t i = 0; i < count; i++) {
+                    if (COUNT) cnt.tris++;
+                    test_triangle(sc.tris, start + i, o, d, hit);
+                    if (anyhit && hit.prim != RT_PRIM_MISS) {
+                        stop = true;
+                        break;
+                    }
+                }
+                if (stop) {
+                    state = ST_SHADOW_DONE;
+                } else if (sp > 0) {
+                    sp--;
+                    cur = stack[sp * WAVE];
+                } else {
+                    state = anyhit ? ST_SHADOW_DONE : ST_CLOSEST_DONE;
+                }
+            }
+            const unsigned long long still = __ballot(state == ST_TRAVERSING);
+            const unsigned long long parked = __ballot(state != ST_TRAVERSING && state != ST_DONE);
+            if (still == 0ull || __popcll(parked) >= RT_SM_PARK_THRESHOLD) break;
+        }
+        if (COUNT) dg_cv += __builtin_readcyclecounter() - t_begin;
+    }
+    unsigned long long c0 = wave_sum(seg.camera), c1 = wave_sum(seg.continuation), c2 = wave_sum(seg.shadow);
+    unsigned long long n0 = COUNT ? wave_sum(cnt.nodes) : 0ull, n1 = COUNT ? wave_sum(cnt.tris) : 0ull;
+    if (threadIdx.x == 0 && tg.counters) {
+        atomicAdd(&tg.counters[0], c0 + c1 + c2);
+        atomicAdd(&tg.counters[3], c0);
+        atomicAdd(&tg.counters[4], c1);
+        atomicAdd(&tg.counters[5], c2);
+        if (COUNT) {
+            atomicAdd(&tg.counters[1], n0);
+            atomicAdd(&tg.counters[2], n1);
+            atomicAdd(&tg.counters[8], dg_tp);
+            atomicAdd(&tg.counters[9], dg_tl);
+            atomicAdd(&tg.counters[10], dg_ni);
+            atomicAdd(&tg.counters[11], dg_nl);
+            atomicAdd(&tg.counters[12], dg_li);
+            atomicAdd(&tg.counters[13], dg_ll);
+            atomicAdd(&tg.counters[14], dg_ct);
+            atomicAdd(&tg.counters[15], dg_cv);
+        }
+    }
+}
+
 } // namespace
 
 namespace rt {
@@ -651,10 +995,18 @@ hipError_t launch_render_extended(const DevScene& sc, const DevFrame& fr, const 
     uint32_t n_tiles = fr.n_owned_tiles;
     if (n_tiles == 0) return hipSuccess;
     dim3 grid(n_tiles * blocks_per_tile(fr.tile_size)), block(WAVE);
-    if (counters)
-        hipLaunchKernelGGL(k_render_extended<true>, grid, block, 0, stream, sc, fr, tg);
-    else
-        hipLaunchKernelGGL(k_render_extended<false>, grid, block, 0, stream, sc, fr, tg);
+    const bool v1 = (fr.flags & 4u) != 0; // RT_FLAG_KERNEL_V1: the nested-loop kernel, kept for A/B runs
+    if (v1) {
+        if (counters)
+            hipLaunchKernelGGL(k_render_extended<true>, grid, block, 0, stream, sc, fr, tg);
+        else
+            hipLaunchKernelGGL(k_render_extended<false>, grid, block, 0, stream, sc, fr, tg);
+    } else {
+        if (counters)
+            hipLaunchKernelGGL(k_render_extended_sm<true>, grid, block, 0, stream, sc, fr, tg);
+        else
+            hipLaunchKernelGGL(k_render_extended_sm<false>, grid, block, 0, stream, sc, fr, tg);
+    }
     return hipGetLastError();
 }
 

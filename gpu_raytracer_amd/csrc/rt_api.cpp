@@ -52,6 +52,7 @@ struct rt_ctx {
     rt_stats stats{};
     uint32_t frame_w = 0, frame_h = 0, frame_tile = RT_TILE_SIZE, frame_tiles_x = 0, frame_tiles_y = 0;
     bool frame_valid = false;
+    unsigned long long diag[8] = {0}; // diagnostics of the counting kernel variant (rt_debug_counters)
 
     int fail(int code, const char* fmt, ...) {
         char buf[512];
@@ -273,7 +274,7 @@ int run_frame(rt_ctx* ctx, DevFrame fr, bool counters, uint32_t world, uint32_t 
             d.tile_stride = stride;
             d.n_owned = f.n_owned_tiles;
         }
-        HIPCHK(ctx, hipMemsetAsync(d.counters, 0, 8 * sizeof(unsigned long long), d.stream));
+        HIPCHK(ctx, hipMemsetAsync(d.counters, 0, 16 * sizeof(unsigned long long), d.stream));
         HIPCHK(ctx, hipEventRecord(d.ev0, d.stream));
         if (f.mode == RT_MODE_EXTENDED)
             HIPCHK(ctx, rt::launch_render_extended(scene_for(ctx, d), f, targets_for(d), counters, d.stream));
@@ -282,7 +283,7 @@ int run_frame(rt_ctx* ctx, DevFrame fr, bool counters, uint32_t world, uint32_t 
         HIPCHK(ctx, hipEventRecord(d.ev1, d.stream));
     }
     double kernel_ms = 0.0;
-    unsigned long long cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long cnt[16] = {0};
     const bool extended = fr.mode == RT_MODE_EXTENDED;
     uint64_t pixels = 0;
     for (size_t j = 0; j < nd; j++) {
@@ -293,9 +294,9 @@ int run_frame(rt_ctx* ctx, DevFrame fr, bool counters, uint32_t world, uint32_t 
         HIPCHK(ctx, hipEventElapsedTime(&ms, d.ev0, d.ev1));
         kernel_ms = std::max(kernel_ms, (double)ms);
         if (counters || extended) {
-            unsigned long long c[8];
+            unsigned long long c[16];
             HIPCHK(ctx, hipMemcpy(c, d.counters, sizeof c, hipMemcpyDeviceToHost));
-            for (int k = 0; k < 8; k++) cnt[k] += c[k];
+            for (int k = 0; k < 16; k++) cnt[k] += c[k];
         }
         if (single_tile) {
             pixels += (uint64_t)std::min(fr.tile_w, fr.width - std::min(fr.width, fr.tile_off_x)) *
@@ -323,6 +324,7 @@ int run_frame(rt_ctx* ctx, DevFrame fr, bool counters, uint32_t world, uint32_t 
     }
     st.node_visits = counters ? cnt[1] : 0;
     st.tri_tests = counters ? cnt[2] : 0;
+    for (int k = 0; k < 8; k++) ctx->diag[k] = counters ? cnt[8 + k] : 0;
     st.kernel_ms = kernel_ms;
     st.wall_ms = now_ms() - w0;
     return RT_OK;
@@ -359,7 +361,7 @@ int rt_create(rt_ctx** out, const int* device_ids, int n_devices) {
         }
         if ((e = hipSetDevice(d.device)) != hipSuccess || (e = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking)) != hipSuccess ||
             (e = hipEventCreate(&d.ev0)) != hipSuccess || (e = hipEventCreate(&d.ev1)) != hipSuccess ||
-            (e = hipMalloc((void**)&d.counters, 8 * sizeof(unsigned long long))) != hipSuccess) {
+            (e = hipMalloc((void**)&d.counters, 16 * sizeof(unsigned long long))) != hipSuccess) {
             g_create_error = std::string("rt_create: ") + hipGetErrorString(e);
             ctx->devs.push_back(d);
             rt_destroy(ctx);
@@ -618,6 +620,15 @@ int rt_read_hits(rt_ctx* ctx, uint32_t* prim_ids, float* t, size_t n_pixels) {
         std::memset(t, 0, n * 4);
         if ((rc = gather(ctx, reinterpret_cast<uint8_t*>(t), 4, 5)) != RT_OK) return rc;
     }
+    return RT_OK;
+}
+
+// Development aid (not part of rt_hip.h): wave-level diagnostics of the last RT_FLAG_COUNTERS render of the
+// state-machine kernel: transition passes, lanes served, node iterations, lanes active, leaf iterations, lanes
+// active, cycles in transition phases, cycles in traversal phases (summed over waves).
+int rt_debug_counters(rt_ctx* ctx, unsigned long long out[8]) {
+    if (!ctx || !out) return RT_ERR_BAD_ARG;
+    for (int k = 0; k < 8; k++) out[k] = ctx->diag[k];
     return RT_OK;
 }
 
