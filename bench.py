@@ -230,7 +230,7 @@ def main():
                          "kernel": "k_render_reference" if mode_name == "reference" else "k_render_extended",
                          "kernel_avg_ms": avg_kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
                          "nodes_per_ray": stc["node_visits"] / max(stc["rays"], 1), "tris_per_ray": stc["tri_tests"] / max(stc["rays"], 1),
-                         "note": "algorithmic bytes = node fetches x 64 B + triangle fetches x 48 B + pixels x 36 B (rank 0's share); "
+                         "note": "algorithmic bytes = node fetches x 48 B + triangle fetches x 48 B + pixels x 36 B (rank 0's share); "
                                  "the 23 MB scene is cache resident, so this exceeds what HBM itself moves (see traffic)"},
         }
         if n_gpus == 1 and not args.no_cpu_baseline:

@@ -215,7 +215,7 @@ void build_bvh(const BuildTri* tris_in, size_t n_in, const BvhBuildOptions& opt_
     Builder b;
     b.opt = opt_in;
     if (b.opt.max_leaf < 1) b.opt.max_leaf = 1;
-    if (b.opt.max_leaf > RT_DEV_MAX_LEAF_TRIS) b.opt.max_leaf = RT_DEV_MAX_LEAF_TRIS;
+    if (b.opt.max_leaf > 4) b.opt.max_leaf = 4; // the node format stores (count - 1) of a leaf child in 2 bits
     if (b.opt.max_depth > RT_DEV_MAX_BVH_DEPTH) b.opt.max_depth = RT_DEV_MAX_BVH_DEPTH;
     int hw = (int)std::thread::hardware_concurrency();
     b.max_tasks = std::max(1, (b.opt.threads > 0 ? b.opt.threads : (hw > 0 ? hw : 1)) - 1);
@@ -243,59 +243,117 @@ void build_bvh(const BuildTri* tris_in, size_t n_in, const BvhBuildOptions& opt_
     uint32_t root = b.alloc();
     b.build(root, 0, (uint32_t)n, 0);
 
-    // Emit: triangles in leaf (= ids) order; inner nodes in depth-first pre-order.
+    // ---- collapse to a 4-wide tree and emit it in the quantised layout ----
     out.tris.resize(n);
-    for (size_t i = 0; i < n; i++) put_tri(tris_in[b.ids[i]], &out.tris[i]);
-    auto leaf_ref = [&](const TmpNode& t) { return RT_DEV_LEAF_FLAG | (t.count << RT_DEV_LEAF_COUNT_SHIFT) | t.start; };
+    size_t tri_cursor = 0;
+    auto is_leaf = [&](uint32_t t) { return b.nodes[t].left == 0xFFFFFFFFu; };
+    auto emit_leaf_tris = [&](const TmpNode& t) { // returns the first slot
+        size_t first = tri_cursor;
+        for (uint32_t i = 0; i < t.count; i++) put_tri(tris_in[b.ids[t.start + i]], &out.tris[tri_cursor++]);
+        return (uint32_t)first;
+    };
     const TmpNode& rt_node = b.nodes[root];
-    if (rt_node.left == 0xFFFFFFFFu) { // whole scene fits one leaf
-        out.root_ref = leaf_ref(rt_node);
+    if (is_leaf(root)) { // whole scene fits one leaf
+        uint32_t first = emit_leaf_tris(rt_node);
+        out.root_ref = RT_DEV_LEAF_FLAG | (rt_node.count << RT_DEV_LEAF_COUNT_SHIFT) | first;
         out.n_leaves = 1;
         out.depth = 0;
         return;
     }
-    // count inner nodes, then assign indices iteratively (explicit stack: no deep recursion)
     struct Item {
         uint32_t tmp, dev, depth;
     };
     std::vector<Item> stack;
-    out.nodes.reserve(n);
+    out.nodes.reserve(n / 2 + 1);
     out.nodes.emplace_back();
     stack.push_back({root, 0, 1});
     double cost = 0.0;
-    float root_area = rt_node.box.half_area();
+    const float root_area = rt_node.box.half_area();
     while (!stack.empty()) {
         Item it = stack.back();
         stack.pop_back();
         out.depth = std::max(out.depth, it.depth);
         const TmpNode& t = b.nodes[it.tmp];
-        const TmpNode* ch[2] = {&b.nodes[t.left], &b.nodes[t.right]};
-        uint32_t refs[2];
-        for (int c = 0; c < 2; c++) {
-            if (ch[c]->left == 0xFFFFFFFFu) {
-                refs[c] = leaf_ref(*ch[c]);
-                out.n_leaves++;
-                if (root_area > 0) cost += opt_in.cost_intersect * ch[c]->count * ch[c]->box.half_area() / root_area;
-            } else {
-                refs[c] = (uint32_t)out.nodes.size();
-                out.nodes.emplace_back();
-                if (root_area > 0) cost += opt_in.cost_traverse * ch[c]->box.half_area() / root_area;
-            }
+        // open the child with the largest surface area until the node has four children
+        uint32_t ch[4] = {t.left, t.right, 0, 0};
+        int nch = 2;
+        while (nch < 4) {
+            int best = -1;
+            float best_area = -1.0f;
+            for (int c = 0; c < nch; c++)
+                if (!is_leaf(ch[c]) && b.nodes[ch[c]].box.half_area() > best_area) {
+                    best_area = b.nodes[ch[c]].box.half_area();
+                    best = c;
+                }
+            if (best < 0) break;
+            uint32_t open = ch[best];
+            ch[best] = b.nodes[open].left;
+            ch[nch++] = b.nodes[open].right;
         }
-        // right pushed first so the left subtree is laid out right after its parent
-        if (!(refs[1] & RT_DEV_LEAF_FLAG)) stack.push_back({t.right, refs[1], it.depth + 1});
-        if (!(refs[0] & RT_DEV_LEAF_FLAG)) stack.push_back({t.left, refs[0], it.depth + 1});
-        DevNode& d = out.nodes[it.dev];
-        std::memcpy(d.c0_min, ch[0]->box.mn, 12);
-        std::memcpy(d.c0_max, ch[0]->box.mx, 12);
-        std::memcpy(d.c1_min, ch[1]->box.mn, 12);
-        std::memcpy(d.c1_max, ch[1]->box.mx, 12);
-        d.child0 = refs[0];
-        d.child1 = refs[1];
-        d._pad0 = d._pad1 = 0;
+        // inner children first, then leaves (the kernel derives child kinds from the two counts)
+        uint32_t ordered[4];
+        int n_inner = 0, k = 0;
+        for (int c = 0; c < nch; c++)
+            if (!is_leaf(ch[c])) ordered[k++] = ch[c];
+        n_inner = k;
+        for (int c = 0; c < nch; c++)
+            if (is_leaf(ch[c])) ordered[k++] = ch[c];
+        const uint32_t node_base = (uint32_t)out.nodes.size();
+        for (int c = 0; c < n_inner; c++) out.nodes.emplace_back();
+        const uint32_t tri_base = (uint32_t)tri_cursor;
+        uint32_t cnt_bits = 0;
+        for (int c = n_inner; c < nch; c++) {
+            const TmpNode& lf = b.nodes[ordered[c]];
+            emit_leaf_tris(lf);
+            cnt_bits |= ((lf.count - 1u) & 3u) << (2 * (c - n_inner));
+            out.n_leaves++;
+            if (root_area > 0) cost += opt_in.cost_intersect * lf.count * lf.box.half_area() / root_area;
+        }
+        for (int c = n_inner - 1; c >= 0; c--) stack.push_back({ordered[c], node_base + (uint32_t)c, it.depth + 1});
+        if (root_area > 0) cost += opt_in.cost_traverse * t.box.half_area() / root_area;
+
+        // quantise the children's boxes on a per-node grid: plane = org + q * 2^(e-127), q in [0,255], rounded outward
+        DevNode4& d = out.nodes[it.dev];
+        uint32_t ex[3];
+        for (int a = 0; a < 3; a++) {
+            d.org[a] = t.box.mn[a];
+            double extent = (double)t.box.mx[a] - (double)t.box.mn[a];
+            int e = 1; // 2^-126: every plane coincides with the origin
+            if (extent > 0.0) {
+                int fe;
+                std::frexp(extent / 255.0, &fe); // extent/255 = m * 2^fe, m in [0.5,1)  =>  2^fe >= extent/255
+                e = fe + 127;
+                if (e < 1) e = 1;
+                if (e > 254) e = 254;
+            }
+            ex[a] = (uint32_t)e;
+            const double scale = std::ldexp(1.0, e - 127);
+            uint32_t lo_word = 0, hi_word = 0;
+            for (int c = 0; c < 4; c++) {
+                uint32_t qlo = 255, qhi = 0; // absent child: inverted, never hit
+                if (c < nch) {
+                    const Box& cb = b.nodes[ordered[c]].box;
+                    double lo = std::floor(((double)cb.mn[a] - (double)d.org[a]) / scale);
+                    double hi = std::ceil(((double)cb.mx[a] - (double)d.org[a]) / scale);
+                    lo = std::min(std::max(lo, 0.0), 255.0);
+                    hi = std::min(std::max(hi, 0.0), 255.0);
+                    while (lo > 0.0 && (double)d.org[a] + lo * scale > (double)cb.mn[a]) lo -= 1.0;
+                    while (hi < 255.0 && (double)d.org[a] + hi * scale < (double)cb.mx[a]) hi += 1.0;
+                    qlo = (uint32_t)lo;
+                    qhi = (uint32_t)hi;
+                }
+                lo_word |= qlo << (8 * c);
+                hi_word |= qhi << (8 * c);
+            }
+            d.qlo[a] = lo_word;
+            d.qhi[a] = hi_word;
+        }
+        d.ex_cnt = ex[0] | (ex[1] << 8) | (ex[2] << 16) | (cnt_bits << 24);
+        d.base_inf = (node_base & RT_DEV_NODE_BASE_MASK) | ((uint32_t)n_inner << 26) | ((uint32_t)nch << 29);
+        d.tri_base = tri_base;
     }
     out.root_ref = 0;
-    out.sah_cost = cost + opt_in.cost_traverse;
+    out.sah_cost = cost;
 }
 
 } // namespace rt

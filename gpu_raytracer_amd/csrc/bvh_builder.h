@@ -4,8 +4,9 @@
 // src/bvh.rs:125-151) or in mesh-order chunks of 32+ triangles (> 100k, :154-247) and
 // its kernel neither orders children nor culls by the closest hit
 // (shader/src/bvh.rs:40-85).  Closest-hit results do not depend on topology, so the
-// library builds its own: binned-SAH BVH2, <= 4 triangles per leaf, bounded depth,
-// emitted in the 64-byte two-child-box node layout of device_layout.h.
+// library builds its own: binned-SAH binary tree, <= 4 triangles per leaf, bounded depth,
+// collapsed into a 4-wide tree (the child with the largest surface area is opened until a
+// node has four children) and emitted in the 48-byte quantised layout of device_layout.h.
 #ifndef RT_BVH_BUILDER_H
 #define RT_BVH_BUILDER_H
 
@@ -24,10 +25,10 @@ struct BuildTri {
 };
 
 struct BvhBuild {
-    std::vector<DevNode> nodes;
+    std::vector<DevNode4> nodes;
     std::vector<DevTri> tris; // leaf order
     uint32_t root_ref = RT_DEV_LEAF_FLAG; // empty leaf
-    uint32_t depth = 0;                   // inner-node levels on the longest root-to-leaf path
+    uint32_t depth = 0;                   // inner-node levels of the 4-wide tree on the longest root-to-leaf path
     uint32_t n_leaves = 0;
     double sah_cost = 0.0;
 };

@@ -1,15 +1,18 @@
 // device_layout.h — HBM layout of the scene as the HIP kernels read it.
 //
 // The reference kernel reads a 48-byte AoS BvhNode as 8-10 scalar u32 loads per
-// visit (shader/src/scene_access.rs:110-159) and reaches a triangle through three
-// dependent gathers: index -> Triangle -> 3 x Vertex = 56 bytes
+// visit (shader/src/scene_access.rs:110-159), two visits per tree level, and reaches a
+// triangle through three dependent gathers: index -> Triangle -> 3 x Vertex = 56 bytes
 // (shader/src/bvh.rs:113-122, triangle_access.rs:26-47).  Here:
 //
-//   DevNode  64 B, one per INNER node, holding BOTH child boxes and both child
-//            references: one aligned 64-byte fetch (4 x dwordx4) per traversal
-//            step instead of two 48-byte node reads.  Leaves have no node record:
-//            a leaf is a (start,count) run in the triangle array, encoded in the
-//            parent's child reference.
+//   DevNode4 48 B, one per INNER node of a 4-wide BVH: the boxes of up to four children,
+//            quantised to 8 bits per plane on a per-node grid (origin + power-of-two scale per
+//            axis, boxes rounded outward), plus two base indices.  One visit = 3 x dwordx4 and
+//            replaces two to three visits of a binary tree.  Measured reason: the
+//            traversal is bound by vector-memory instructions per segment, so fewer and narrower
+//            node fetches are what pays.  Quantised boxes are supersets of the exact ones: they
+//            only filter, every hit is decided by the triangle test, results are unchanged.
+//            Leaves have no node record: a leaf is a (start,count) run of the triangle array.
 //   DevTri   48 B, pre-gathered (v0, e1 = v1-v0, e2 = v2-v0, material, original
 //            index) stored in leaf order: one contiguous 48-byte read (3 x dwordx4)
 //            per triangle test.  e1/e2 are the same f32 subtractions the reference
@@ -24,22 +27,26 @@
 #define RT_DEV_LEAF_START_MASK 0x07FFFFFFu
 #define RT_DEV_MAX_LEAF_TRIS 15u
 #define RT_DEV_MAX_TRIS 0x07FFFFFFu
-#define RT_DEV_STACK_DEPTH 32 /* per-lane traversal stack entries held in LDS */
-#define RT_DEV_MAX_BVH_DEPTH 32 /* builder guarantee: inner-node depth <= this, so the stack cannot overflow */
+#define RT_DEV_MAX_BVH_DEPTH 32 /* binary build depth bound; the 4-wide tree is at most this deep */
+/* A visit of a 4-wide node pushes at most 3 references, so a tree of depth D needs 3*D + 1 stack entries per lane.
+   The stack lives in dynamic LDS sized from the depth of the uploaded tree (DevScene::stack_entries). */
+#define RT_DEV_MAX_STACK_ENTRIES (3 * RT_DEV_MAX_BVH_DEPTH + 1)
 
 #define RT_PRIM_MISS 0xFFFFFFFFu
 #define RT_PRIM_SPHERE_FLAG 0x80000000u
 
-struct DevNode { // 64 bytes, 64-byte aligned
-    float c0_min[3];
-    uint32_t child0; // inner: node index; leaf: RT_DEV_LEAF_FLAG | count << 27 | start
-    float c0_max[3];
-    uint32_t child1;
-    float c1_min[3];
-    uint32_t _pad0;
-    float c1_max[3];
-    uint32_t _pad1;
+// Traversal references (stack entries, root_ref): bit 31 clear = inner node index;
+// bit 31 set = leaf: RT_DEV_LEAF_FLAG | count << 27 | first triangle.
+struct DevNode4 { // 48 bytes, 16-byte aligned
+    float org[3];      // quantisation origin (the node's box minimum)
+    uint32_t ex_cnt;   // byte 0..2: exponent e of axis x,y,z (plane = org + q * 2^(e-127)); byte 3: (count-1) of leaf child j in bits 2j..2j+1
+    uint32_t base_inf; // bits 0..25 index of the first inner child (inner children are consecutive); 26..28 n_inner; 29..31 n_children
+    uint32_t tri_base; // first triangle of the first leaf child (leaf children's triangles are consecutive, in child order)
+    uint32_t qlo[3];   // [axis]: byte i = quantised lower plane of child i (children: inner ones first, then leaves)
+    uint32_t qhi[3];   // [axis]: byte i = quantised upper plane of child i; absent children are inverted (lo 255, hi 0)
 };
+#define RT_DEV_NODE_BASE_MASK 0x03FFFFFFu
+#define RT_DEV_MAX_NODES 0x03FFFFFFu
 
 struct DevTri { // 48 bytes, 16-byte aligned
     float v0[3];
@@ -77,7 +84,7 @@ struct DevLight { // 48 bytes: the 11 words of Light the kernel reads (shader/sr
 };
 
 struct DevScene {
-    const DevNode* nodes;
+    const DevNode4* nodes;
     const DevTri* tris;
     const DevSphere* spheres;
     const DevLight* lights;
@@ -88,6 +95,7 @@ struct DevScene {
     uint32_t n_lights;
     uint32_t n_materials; // `materials.len()` of shader/src/lib.rs:307 := material_count
     uint32_t root_ref;    // child reference of the root (a leaf reference for tiny scenes)
+    uint32_t stack_entries; // per-lane LDS stack entries the kernels must provide: 3 * depth + 1
 };
 
 // Camera terms that do not depend on the pixel, computed once on the host in the

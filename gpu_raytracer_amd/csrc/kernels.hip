@@ -136,66 +136,139 @@ __device__ __forceinline__ void test_triangle(const DevTri* __restrict__ tris, u
 }
 
 // ------------------------------------------------------------------------------------
-// BVH traversal.  Replaces BvhTraverser::traverse_and_intersect (shader/src/bvh.rs:18-88):
-// per-lane depth-first walk over 64-byte two-child nodes, nearer child first, children
-// whose entry distance exceeds the closest hit are skipped (result-neutral: the reference's
-// slab test ignores the closest hit, shader/src/intersection.rs:151-164, and so visits a
-// superset).  The stack lives in LDS, lane-interleaved (entry k of lane l at
-// stack[k * 64 + l]): ds_read/write_b32 with consecutive lanes on consecutive banks.
-// Depth cannot exceed RT_DEV_STACK_DEPTH: the builder bounds the tree depth.
+// BVH traversal.  Replaces BvhTraverser::traverse_and_intersect (shader/src/bvh.rs:18-88) and
+// ray_aabb_intersect (shader/src/intersection.rs:151-164): per-lane depth-first walk over the
+// 4-wide quantised tree of device_layout.h.  A visit fetches one 48-byte node (3 x dwordx4),
+// slab-tests its (up to) four children, continues with the nearest hit child and pushes the others
+// far-to-near.  Children whose entry distance exceeds the closest hit are skipped (the reference's
+// slab test ignores the closest hit and so visits a superset: result-neutral).
+//
+// The boxes are FILTERS only — which primitive is hit is decided by the reference's
+// Möller–Trumbore arithmetic — so they may be conservative but must never be too small.  The
+// quantised planes are rounded outward by the builder; the float evaluation here is widened by a
+// bound on its own rounding error: with a = scale/d, b = (org - o)/d the plane distances are
+// fma(q, a, b), whose absolute error is below 2^-22 * (|org - o| + 255 * scale) / |d| (one rounding
+// each in org - o, a, b, and the fma): near planes are moved back and far planes forward by that.
+//
+// The stack lives in LDS, lane-interleaved (entry k of lane l at stack[k * 64 + l]): ds_read /
+// ds_write_b32 with consecutive lanes on consecutive banks.  A visit pushes at most 3 entries, the
+// launch provides 3 * depth + 1 entries per lane (DevScene::stack_entries), so it cannot overflow.
 // ------------------------------------------------------------------------------------
+struct FilterRay { // per-segment constants of the box filter
+    V3 o, inv;     // inv = 1/d with |d| clamped away from zero (a filter may do that; the triangle test uses the real d)
+};
+__device__ __forceinline__ FilterRay make_filter_ray(V3 o, V3 d) {
+    FilterRay f;
+    f.o = o;
+    float dx = fabsf(d.x) < 1e-30f ? copysignf(1e-30f, d.x) : d.x;
+    float dy = fabsf(d.y) < 1e-30f ? copysignf(1e-30f, d.y) : d.y;
+    float dz = fabsf(d.z) < 1e-30f ? copysignf(1e-30f, d.z) : d.z;
+    f.inv = v3(1.0f / dx, 1.0f / dy, 1.0f / dz);
+    return f;
+}
+
+#define RT_SWAP_IF(cond, ta, tb, ra, rb) \
+    {                                    \
+        const bool c_ = (cond);          \
+        const float tt_ = c_ ? tb : ta;  \
+        tb = c_ ? ta : tb;               \
+        ta = tt_;                        \
+        const uint32_t rr_ = c_ ? rb : ra; \
+        rb = c_ ? ra : rb;               \
+        ra = rr_;                        \
+    }
+
+// One visit of inner node `cur`.  Updates cur / the stack; returns false when the walk is exhausted.
+template <bool COUNT>
+__device__ __forceinline__ bool visit_node4(const uint4* __restrict__ nodes, uint32_t stack_entries, const FilterRay& fr, float closest_t,
+                                            uint32_t* __restrict__ stack, int& sp, uint32_t& cur, Counts& cnt) {
+    const uint4* n = nodes + (size_t)cur * 3;
+    const uint4 w0 = n[0], w1 = n[1], w2 = n[2];
+    if (COUNT) cnt.nodes++;
+    const float scx = __uint_as_float((w0.w & 0xFFu) << 23), scy = __uint_as_float(((w0.w >> 8) & 0xFFu) << 23),
+                scz = __uint_as_float(((w0.w >> 16) & 0xFFu) << 23);
+    const float dox = __uint_as_float(w0.x) - fr.o.x, doy = __uint_as_float(w0.y) - fr.o.y, doz = __uint_as_float(w0.z) - fr.o.z;
+    const float ax = scx * fr.inv.x, ay = scy * fr.inv.y, az = scz * fr.inv.z;
+    const float bx = dox * fr.inv.x, by = doy * fr.inv.y, bz = doz * fr.inv.z;
+    const float ex = (fabsf(dox) + 255.0f * scx) * 2.4e-7f * fabsf(fr.inv.x);
+    const float ey = (fabsf(doy) + 255.0f * scy) * 2.4e-7f * fabsf(fr.inv.y);
+    const float ez = (fabsf(doz) + 255.0f * scz) * 2.4e-7f * fabsf(fr.inv.z);
+    const float bnx = bx - ex, bfx = bx + ex, bny = by - ey, bfy = by + ey, bnz = bz - ez, bfz = bz + ez;
+    // entry planes are the lower ones along axes the ray travels in +, the upper ones otherwise
+    const bool px = fr.inv.x >= 0.0f, py = fr.inv.y >= 0.0f, pz = fr.inv.z >= 0.0f;
+    const uint32_t nxw = px ? w1.z : w2.y, fxw = px ? w2.y : w1.z; // w1.z qlo_x, w2.y qhi_x
+    const uint32_t nyw = py ? w1.w : w2.z, fyw = py ? w2.z : w1.w; // w1.w qlo_y, w2.z qhi_y
+    const uint32_t nzw = pz ? w2.x : w2.w, fzw = pz ? w2.w : w2.x; // w2.x qlo_z, w2.w qhi_z
+    const float limit = closest_t * 1.0000153f; // culling with slack, so equal-t candidates are still visited
+    float t[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float tnx = fmaf((float)((nxw >> (8 * i)) & 0xFFu), ax, bnx), tfx = fmaf((float)((fxw >> (8 * i)) & 0xFFu), ax, bfx);
+        const float tny = fmaf((float)((nyw >> (8 * i)) & 0xFFu), ay, bny), tfy = fmaf((float)((fyw >> (8 * i)) & 0xFFu), ay, bfy);
+        const float tnz = fmaf((float)((nzw >> (8 * i)) & 0xFFu), az, bnz), tfz = fmaf((float)((fzw >> (8 * i)) & 0xFFu), az, bfz);
+        const float tmin = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
+        const float tmax = fminf(fminf(tfx, tfy), fminf(tfz, limit));
+        t[i] = (tmin <= tmax * 1.000001f) ? tmin : RT_F32_MAX; // absent children are inverted boxes: never hit
+    }
+    // child references: inner children first (node_base + i), then leaves (consecutive triangle runs)
+    const uint32_t node_base = w1.x & RT_DEV_NODE_BASE_MASK, n_inner = (w1.x >> 26) & 7u;
+    const uint32_t cb = w0.w >> 24; // (count - 1) of leaf child j in bits 2j..2j+1
+    const uint32_t c0 = (cb & 3u) + 1u, c1 = ((cb >> 2) & 3u) + 1u, c2 = ((cb >> 4) & 3u) + 1u, c3 = ((cb >> 6) & 3u) + 1u;
+    const uint32_t l0 = RT_DEV_LEAF_FLAG | (c0 << RT_DEV_LEAF_COUNT_SHIFT) | w1.y;
+    const uint32_t l1 = RT_DEV_LEAF_FLAG | (c1 << RT_DEV_LEAF_COUNT_SHIFT) | (w1.y + c0);
+    const uint32_t l2 = RT_DEV_LEAF_FLAG | (c2 << RT_DEV_LEAF_COUNT_SHIFT) | (w1.y + c0 + c1);
+    const uint32_t l3 = RT_DEV_LEAF_FLAG | (c3 << RT_DEV_LEAF_COUNT_SHIFT) | (w1.y + c0 + c1 + c2);
+    uint32_t r0, r1, r2, r3; // leaf j is child n_inner + j
+    r0 = n_inner > 0u ? node_base : l0;
+    r1 = n_inner > 1u ? node_base + 1u : (n_inner == 1u ? l0 : l1);
+    r2 = n_inner > 2u ? node_base + 2u : (n_inner == 2u ? l0 : (n_inner == 1u ? l1 : l2));
+    r3 = n_inner > 3u ? node_base + 3u : (n_inner == 3u ? l0 : (n_inner == 2u ? l1 : (n_inner == 1u ? l2 : l3)));
+    float t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
+    // sort the four (distance, reference) pairs by distance: misses (F32_MAX) end up last
+    RT_SWAP_IF(t1 < t0, t0, t1, r0, r1)
+    RT_SWAP_IF(t3 < t2, t2, t3, r2, r3)
+    RT_SWAP_IF(t2 < t0, t0, t2, r0, r2)
+    RT_SWAP_IF(t3 < t1, t1, t3, r1, r3)
+    RT_SWAP_IF(t2 < t1, t1, t2, r1, r2)
+    if (t0 == RT_F32_MAX) { // nothing hit: continue with the stack
+        if (sp == 0) return false;
+        sp--;
+        cur = stack[sp * WAVE];
+        return true;
+    }
+    cur = r0;
+    // push the other hits far-to-near without branching: always store three words (the launch provides three
+    // spare entries), advance the pointer by the number of real ones
+    const int extra = (t1 != RT_F32_MAX ? 1 : 0) + (t2 != RT_F32_MAX ? 1 : 0) + (t3 != RT_F32_MAX ? 1 : 0);
+    const uint32_t e0 = extra == 3 ? r3 : (extra == 2 ? r2 : r1);
+    const uint32_t e1 = extra == 3 ? r2 : r1;
+    stack[sp * WAVE] = e0;
+    stack[(sp + 1) * WAVE] = e1;
+    stack[(sp + 2) * WAVE] = r1;
+    sp += extra;
+    (void)stack_entries;
+    return true;
+}
+
 // ANY_HIT (shadow segments of the extended mode): return at the first accepted triangle.
 template <bool COUNT, bool ANY_HIT>
 __device__ __forceinline__ void traverse(const DevScene& sc, V3 o, V3 d, uint32_t* __restrict__ stack, Hit& hit, Counts& cnt) {
     if (sc.n_tris == 0) return;
-    const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); // ray_aabb_intersect recomputes this per node (:152)
-    const float4* __restrict__ nodes = reinterpret_cast<const float4*>(sc.nodes);
+    const FilterRay fr = make_filter_ray(o, d);
+    const uint4* __restrict__ nodes = reinterpret_cast<const uint4*>(sc.nodes);
     uint32_t cur = sc.root_ref;
     int sp = 0;
     for (;;) {
         if (!(cur & RT_DEV_LEAF_FLAG)) {
-            const float4* n = nodes + (size_t)cur * 4;
-            float4 a = n[0], b = n[1], c = n[2], e = n[3];
-            if (COUNT) cnt.nodes++;
-            // ray_aabb_intersect (shader/src/intersection.rs:151-164) on both children
-            float t0x = (a.x - o.x) * inv.x, t0y = (a.y - o.y) * inv.y, t0z = (a.z - o.z) * inv.z;
-            float t1x = (b.x - o.x) * inv.x, t1y = (b.y - o.y) * inv.y, t1z = (b.z - o.z) * inv.z;
-            float u0x = (c.x - o.x) * inv.x, u0y = (c.y - o.y) * inv.y, u0z = (c.z - o.z) * inv.z;
-            float u1x = (e.x - o.x) * inv.x, u1y = (e.y - o.y) * inv.y, u1z = (e.z - o.z) * inv.z;
-            // fminf/fmaxf are NaN-suppressing like Rust f32::min/max
-            float tmin0 = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
-            float tmax0 = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
-            float tmin1 = fmaxf(fmaxf(fminf(u0x, u1x), fminf(u0y, u1y)), fminf(u0z, u1z));
-            float tmax1 = fminf(fminf(fmaxf(u0x, u1x), fmaxf(u0y, u1y)), fmaxf(u0z, u1z));
-            // the reference's acceptance, plus culling against the closest hit (with slack so that
-            // equal-t candidates are still visited)
-            float limit = hit.t * 1.0000153f;
-            bool h0 = tmax0 >= 0.0f && tmin0 <= tmax0 && tmin0 <= limit;
-            bool h1 = tmax1 >= 0.0f && tmin1 <= tmax1 && tmin1 <= limit;
-            uint32_t c0 = __float_as_uint(a.w), c1 = __float_as_uint(b.w);
-            if (h0 && h1) {
-                bool first0 = tmin0 <= tmin1;
-                if (sp < RT_DEV_STACK_DEPTH) { // cannot trigger: the builder bounds the depth
-                    stack[sp * WAVE] = first0 ? c1 : c0;
-                    sp++;
-                }
-                cur = first0 ? c0 : c1;
-                continue;
-            } else if (h0) {
-                cur = c0;
-                continue;
-            } else if (h1) {
-                cur = c1;
-                continue;
-            }
-        } else {
-            uint32_t start = cur & RT_DEV_LEAF_START_MASK;
-            uint32_t count = (cur >> RT_DEV_LEAF_COUNT_SHIFT) & 0xFu;
-            for (uint32_t i = 0; i < count; i++) {
-                if (COUNT) cnt.tris++;
-                test_triangle(sc.tris, start + i, o, d, hit);
-                if (ANY_HIT && hit.prim != RT_PRIM_MISS) return;
-            }
+            if (!visit_node4<COUNT>(nodes, sc.stack_entries, fr, hit.t, stack, sp, cur, cnt)) break;
+            continue;
+        }
+        uint32_t start = cur & RT_DEV_LEAF_START_MASK;
+        uint32_t count = (cur >> RT_DEV_LEAF_COUNT_SHIFT) & 0xFu;
+        for (uint32_t i = 0; i < count; i++) {
+            if (COUNT) cnt.tris++;
+            test_triangle(sc.tris, start + i, o, d, hit);
+            if (ANY_HIT && hit.prim != RT_PRIM_MISS) return;
         }
         if (sp == 0) break;
         sp--;
@@ -354,7 +427,7 @@ __device__ __forceinline__ PixelCoord block_pixel(const DevFrame& fr) {
 // ------------------------------------------------------------------------------------
 template <bool COUNT>
 __global__ __launch_bounds__(WAVE) void k_render_reference(DevScene sc, DevFrame fr, DevTargets tg) {
-    __shared__ uint32_t s_stack[RT_DEV_STACK_DEPTH * WAVE];
+    extern __shared__ uint32_t s_stack[]; // DevScene::stack_entries * 64 words
     PixelCoord px = block_pixel(fr);
     if (!px.valid) return;
     uint32_t* stack = s_stack + threadIdx.x;
@@ -596,7 +669,7 @@ __device__ __forceinline__ unsigned long long wave_sum(uint32_t v) {
 
 template <bool COUNT>
 __global__ __launch_bounds__(WAVE) void k_render_extended(DevScene sc, DevFrame fr, DevTargets tg) {
-    __shared__ uint32_t s_stack[RT_DEV_STACK_DEPTH * WAVE];
+    extern __shared__ uint32_t s_stack[]; // DevScene::stack_entries * 64 words
     PixelCoord px = block_pixel(fr);
     uint32_t* stack = s_stack + threadIdx.x;
     Counts cnt = {0u, 0u};
@@ -647,6 +720,13 @@ __global__ __launch_bounds__(WAVE) void k_render_extended(DevScene sc, DevFrame 
 #ifndef RT_SM_MIN_WAVES
 #define RT_SM_MIN_WAVES 4
 #endif
+#ifndef RT_SM_SPECULATIVE
+#define RT_SM_SPECULATIVE 0
+#endif
+#ifndef RT_SM_LEAF_THRESHOLD
+#define RT_SM_LEAF_THRESHOLD 24
+#endif
+#define REF_NONE RT_DEV_LEAF_FLAG /* an empty leaf reference: "nothing to visit" */
 #ifndef RT_SM_PARK_THRESHOLD
 #define RT_SM_PARK_THRESHOLD 8
 #endif
@@ -655,10 +735,10 @@ enum : uint32_t { ST_NEW_SAMPLE = 0, ST_CLOSEST_DONE = 1, ST_SHADOW_DONE = 2, ST
 
 template <bool COUNT>
 __global__ __launch_bounds__(WAVE, RT_SM_MIN_WAVES) void k_render_extended_sm(DevScene sc, DevFrame fr, DevTargets tg) {
-    __shared__ uint32_t s_stack[RT_DEV_STACK_DEPTH * WAVE];
+    extern __shared__ uint32_t s_stack[]; // DevScene::stack_entries * 64 words
     const PixelCoord px = block_pixel(fr);
     uint32_t* __restrict__ stack = s_stack + threadIdx.x;
-    const float4* __restrict__ nodes = reinterpret_cast<const float4*>(sc.nodes);
+    const uint4* __restrict__ nodes = reinterpret_cast<const uint4*>(sc.nodes);
     Counts cnt = {0u, 0u};
     SegCounts seg = {0u, 0u, 0u};
     const bool shadows = (fr.flags & 2u) == 0;
@@ -671,12 +751,15 @@ __global__ __launch_bounds__(WAVE, RT_SM_MIN_WAVES) void k_render_extended_sm(De
     V3 point = sum, normal = sum, din = sum; // vertex position, geometric normal, incoming direction
     bool terminal = false;
     // ---- per-lane segment (traversal) state ----
-    V3 o = sum, d = sum, inv = sum;
+    V3 o = sum, d = sum;
+    FilterRay fray;
+    fray.o = sum;
+    fray.inv = sum;
     Hit hit;
     hit.t = RT_F32_MAX;
     hit.prim = RT_PRIM_MISS;
     hit.slot = 0;
-    uint32_t cur = 0;
+    uint32_t cur = REF_NONE, pleaf = REF_NONE;
     int sp = 0;
     bool anyhit = false;
 
@@ -684,7 +767,7 @@ __global__ __launch_bounds__(WAVE, RT_SM_MIN_WAVES) void k_render_extended_sm(De
     auto begin_segment = [&](V3 so, V3 sd, float tmax, bool any) {
         o = so;
         d = sd;
-        inv = v3(1.0f / sd.x, 1.0f / sd.y, 1.0f / sd.z);
+        fray = make_filter_ray(so, sd);
         hit.t = tmax;
         hit.prim = RT_PRIM_MISS;
         hit.slot = 0;
@@ -692,6 +775,7 @@ __global__ __launch_bounds__(WAVE, RT_SM_MIN_WAVES) void k_render_extended_sm(De
         test_spheres(sc, so, sd, hit);
         sp = 0;
         cur = sc.root_ref;
+        pleaf = REF_NONE;
         const bool finished = sc.n_tris == 0 || (any && hit.prim != RT_PRIM_MISS);
         state = finished ? (any ? ST_SHADOW_DONE : ST_CLOSEST_DONE) : ST_TRAVERSING;
     };
@@ -867,6 +951,59 @@ __global__ __launch_bounds__(WAVE, RT_SM_MIN_WAVES) void k_render_extended_sm(De
             continue;
         }
         // =========================== traversal phase ===========================
+#if RT_SM_SPECULATIVE
+        // Speculative descent with one postponed leaf per lane: a lane that reaches a leaf parks the leaf
+        // reference in `pleaf` and keeps walking (pops its next subtree) instead of waiting for the other lanes
+        // to reach theirs; the triangle tests run for many lanes at once when RT_SM_LEAF_THRESHOLD lanes hold a
+        // postponed leaf or no lane can take a node step.  Closest hit (and "any hit" existence) do not depend
+        // on the order in which leaves are tested - ties go to the lower triangle index - so this is
+        // result-neutral; its only cost is that culling sees the closest hit a little later.
+        for (;;) {
+            const bool trav = state == ST_TRAVERSING;
+            if (trav && (cur & RT_DEV_LEAF_FLAG) && cur != REF_NONE && pleaf == REF_NONE) {
+                pleaf = cur;
+                if (sp > 0) {
+                    sp--;
+                    cur = stack[sp * WAVE];
+                } else {
+                    cur = REF_NONE;
+                }
+            }
+            const bool can_node = trav && !(cur & RT_DEV_LEAF_FLAG);
+            const bool has_leaf = trav && pleaf != REF_NONE;
+            const unsigned long long m_node = __ballot(can_node);
+            const unsigned long long m_leaf = __ballot(has_leaf);
+            if (m_node != 0ull && __popcll(m_leaf) < RT_SM_LEAF_THRESHOLD) {
+                if (COUNT) {
+                    dg_ni++;
+                    dg_nl += __popcll(m_node);
+                }
+                if (can_node) {
+                    if (!visit_node4<COUNT>(nodes, sc.stack_entries, fray, hit.t, stack, sp, cur, cnt)) cur = REF_NONE;
+                }
+            } else if (m_leaf != 0ull) {
+                if (COUNT) {
+                    dg_li++;
+                    dg_ll += __popcll(m_leaf);
+                }
+                if (has_leaf) {
+                    uint32_t start = pleaf & RT_DEV_LEAF_START_MASK;
+                    uint32_t count = (pleaf >> RT_DEV_LEAF_COUNT_SHIFT) & 0xFu;
+                    pleaf = REF_NONE;
+                    for (uint32_t i = 0; i < count; i++) {
+                        if (COUNT) cnt.tris++;
+                        test_triangle(sc.tris, start + i, o, d, hit);
+                        if (anyhit && hit.prim != RT_PRIM_MISS) break;
+                    }
+                    if (anyhit && hit.prim != RT_PRIM_MISS) state = ST_SHADOW_DONE;
+                }
+            }
+            if (state == ST_TRAVERSING && cur == REF_NONE && pleaf == REF_NONE) state = anyhit ? ST_SHADOW_DONE : ST_CLOSEST_DONE;
+            const unsigned long long still = __ballot(state == ST_TRAVERSING);
+            const unsigned long long parked = __ballot(state != ST_TRAVERSING && state != ST_DONE);
+            if (still == 0ull || __popcll(parked) >= RT_SM_PARK_THRESHOLD) break;
+        }
+#else
         // while-while: all lanes that stand on an inner node step until none does, then the lanes that reached
         // a leaf test its triangles.  (A speculative variant that postpones one leaf per lane and keeps
         // descending raised lane utilisation of the node steps from 26 % to 48 % but was not faster: the
@@ -881,38 +1018,8 @@ __global__ __launch_bounds__(WAVE, RT_SM_MIN_WAVES) void k_render_extended_sm(De
                     dg_nl += __popcll(wmask);
                 }
                 if (want) {
-                    const float4* n = nodes + (size_t)cur * 4;
-                    float4 a = n[0], b = n[1], c = n[2], e = n[3];
-                    if (COUNT) cnt.nodes++;
-                    float t0x = (a.x - o.x) * inv.x, t0y = (a.y - o.y) * inv.y, t0z = (a.z - o.z) * inv.z;
-                    float t1x = (b.x - o.x) * inv.x, t1y = (b.y - o.y) * inv.y, t1z = (b.z - o.z) * inv.z;
-                    float u0x = (c.x - o.x) * inv.x, u0y = (c.y - o.y) * inv.y, u0z = (c.z - o.z) * inv.z;
-                    float u1x = (e.x - o.x) * inv.x, u1y = (e.y - o.y) * inv.y, u1z = (e.z - o.z) * inv.z;
-                    float tmin0 = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
-                    float tmax0 = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
-                    float tmin1 = fmaxf(fmaxf(fminf(u0x, u1x), fminf(u0y, u1y)), fminf(u0z, u1z));
-                    float tmax1 = fminf(fminf(fmaxf(u0x, u1x), fmaxf(u0y, u1y)), fmaxf(u0z, u1z));
-                    float limit = hit.t * 1.0000153f;
-                    bool h0 = tmax0 >= 0.0f && tmin0 <= tmax0 && tmin0 <= limit;
-                    bool h1 = tmax1 >= 0.0f && tmin1 <= tmax1 && tmin1 <= limit;
-                    uint32_t c0 = __float_as_uint(a.w), c1 = __float_as_uint(b.w);
-                    if (h0 && h1) {
-                        bool first0 = tmin0 <= tmin1;
-                        if (sp < RT_DEV_STACK_DEPTH) {
-                            stack[sp * WAVE] = first0 ? c1 : c0;
-                            sp++;
-                        }
-                        cur = first0 ? c0 : c1;
-                    } else if (h0) {
-                        cur = c0;
-                    } else if (h1) {
-                        cur = c1;
-                    } else if (sp > 0) {
-                        sp--;
-                        cur = stack[sp * WAVE];
-                    } else {
+                    if (!visit_node4<COUNT>(nodes, sc.stack_entries, fray, hit.t, stack, sp, cur, cnt))
                         state = anyhit ? ST_SHADOW_DONE : ST_CLOSEST_DONE;
-                    }
                 }
             }
             if (COUNT) {
@@ -947,6 +1054,7 @@ __global__ __launch_bounds__(WAVE, RT_SM_MIN_WAVES) void k_render_extended_sm(De
             const unsigned long long parked = __ballot(state != ST_TRAVERSING && state != ST_DONE);
             if (still == 0ull || __popcll(parked) >= RT_SM_PARK_THRESHOLD) break;
         }
+#endif
         if (COUNT) dg_cv += __builtin_readcyclecounter() - t_begin;
     }
     unsigned long long c0 = wave_sum(seg.camera), c1 = wave_sum(seg.continuation), c2 = wave_sum(seg.shadow);
@@ -975,6 +1083,8 @@ __global__ __launch_bounds__(WAVE, RT_SM_MIN_WAVES) void k_render_extended_sm(De
 
 namespace rt {
 
+static size_t lds_bytes(const DevScene& sc) { return (size_t)(sc.stack_entries + 3u) * WAVE * sizeof(uint32_t); } // +3: visit_node4 stores three words unconditionally
+
 uint32_t blocks_per_tile(uint32_t tile_size) {
     uint32_t b = (tile_size + 7u) >> 3;
     return b * b;
@@ -985,9 +1095,9 @@ hipError_t launch_render_reference(const DevScene& sc, const DevFrame& fr, const
     if (n_tiles == 0) return hipSuccess;
     dim3 grid(n_tiles * blocks_per_tile(fr.tile_size)), block(WAVE);
     if (counters)
-        hipLaunchKernelGGL(k_render_reference<true>, grid, block, 0, stream, sc, fr, tg);
+        hipLaunchKernelGGL(k_render_reference<true>, grid, block, lds_bytes(sc), stream, sc, fr, tg);
     else
-        hipLaunchKernelGGL(k_render_reference<false>, grid, block, 0, stream, sc, fr, tg);
+        hipLaunchKernelGGL(k_render_reference<false>, grid, block, lds_bytes(sc), stream, sc, fr, tg);
     return hipGetLastError();
 }
 
@@ -998,14 +1108,14 @@ hipError_t launch_render_extended(const DevScene& sc, const DevFrame& fr, const 
     const bool v1 = (fr.flags & 4u) != 0; // RT_FLAG_KERNEL_V1: the nested-loop kernel, kept for A/B runs
     if (v1) {
         if (counters)
-            hipLaunchKernelGGL(k_render_extended<true>, grid, block, 0, stream, sc, fr, tg);
+            hipLaunchKernelGGL(k_render_extended<true>, grid, block, lds_bytes(sc), stream, sc, fr, tg);
         else
-            hipLaunchKernelGGL(k_render_extended<false>, grid, block, 0, stream, sc, fr, tg);
+            hipLaunchKernelGGL(k_render_extended<false>, grid, block, lds_bytes(sc), stream, sc, fr, tg);
     } else {
         if (counters)
-            hipLaunchKernelGGL(k_render_extended_sm<true>, grid, block, 0, stream, sc, fr, tg);
+            hipLaunchKernelGGL(k_render_extended_sm<true>, grid, block, lds_bytes(sc), stream, sc, fr, tg);
         else
-            hipLaunchKernelGGL(k_render_extended_sm<false>, grid, block, 0, stream, sc, fr, tg);
+            hipLaunchKernelGGL(k_render_extended_sm<false>, grid, block, lds_bytes(sc), stream, sc, fr, tg);
     }
     return hipGetLastError();
 }

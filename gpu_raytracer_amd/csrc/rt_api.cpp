@@ -28,7 +28,7 @@ struct DeviceState {
     int device = -1;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    DevNode* nodes = nullptr;
+    DevNode4* nodes = nullptr;
     DevTri* tris = nullptr;
     DevSphere* spheres = nullptr;
     DevLight* lights = nullptr;
@@ -193,7 +193,8 @@ int upload_common(rt_ctx* ctx, const rt_sphere* spheres, uint32_t n_spheres, con
     rt::build_bvh(bt.data(), bt.size(), opt, bvh);
     double build_ms = now_ms() - t0;
     (void)build_ms;
-    if (bvh.depth > RT_DEV_STACK_DEPTH) return ctx->fail(RT_ERR_INTERNAL, "BVH depth %u exceeds the traversal stack %d", bvh.depth, RT_DEV_STACK_DEPTH);
+    if (bvh.depth > RT_DEV_MAX_BVH_DEPTH) return ctx->fail(RT_ERR_INTERNAL, "BVH depth %u exceeds the bound %d", bvh.depth, RT_DEV_MAX_BVH_DEPTH);
+    if (bvh.nodes.size() > RT_DEV_MAX_NODES) return ctx->fail(RT_ERR_BAD_ARG, "scene needs %zu BVH nodes > %u", bvh.nodes.size(), RT_DEV_MAX_NODES);
 
     std::vector<DevSphere> ds(n_spheres);
     for (uint32_t i = 0; i < n_spheres; i++) {
@@ -241,10 +242,11 @@ int upload_common(rt_ctx* ctx, const rt_sphere* spheres, uint32_t n_spheres, con
     sc.n_lights = n_lights;
     sc.n_materials = n_materials;
     sc.root_ref = bvh.root_ref;
+    sc.stack_entries = 3u * bvh.depth + 1u; // a visit pushes at most 3 references
     ctx->stats = rt_stats{};
-    ctx->stats.node_bytes = sizeof(DevNode);
+    ctx->stats.node_bytes = sizeof(DevNode4);
     ctx->stats.tri_bytes = sizeof(DevTri);
-    ctx->stats.scene_bytes = bvh.nodes.size() * sizeof(DevNode) + bvh.tris.size() * sizeof(DevTri) + ds.size() * sizeof(DevSphere) +
+    ctx->stats.scene_bytes = bvh.nodes.size() * sizeof(DevNode4) + bvh.tris.size() * sizeof(DevTri) + ds.size() * sizeof(DevSphere) +
                              dl.size() * sizeof(DevLight) + dm.size() * sizeof(DevMaterial);
     ctx->stats.bvh_nodes = sc.n_nodes;
     ctx->stats.bvh_depth = bvh.depth;
