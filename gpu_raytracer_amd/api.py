@@ -20,6 +20,7 @@ MODE_LEGACY, MODE_WAVEFRONT, MODE_EXTENDED = 0, 1, 2
 FLAG_COUNTERS = 1
 FLAG_NO_SHADOWS = 2
 FLAG_KERNEL_V1 = 4
+FLAG_KERNEL_SM = 8
 EXTENDED_AVAILABLE = True
 
 # every symbol include/rt_hip.h declares
@@ -121,12 +122,12 @@ class Context:
 
     # -- rendering -------------------------------------------------------------------
     def render(self, width, height, camera, mode=MODE_LEGACY, spp=1, max_bounces=4, frame_seed=0, tile_size=0,
-               tile_rank=0, tile_world=1, counters=False, no_shadows=False, kernel_v1=False):
+               tile_rank=0, tile_world=1, counters=False, no_shadows=False, kernel_v1=False, kernel_sm=False):
         p = np.zeros((), dtype=T.RENDER_PARAMS)
         p["camera"] = camera
         p["width"], p["height"], p["spp"], p["max_bounces"], p["mode"] = width, height, spp, max_bounces, mode
         p["frame_seed"], p["tile_size"], p["tile_rank"], p["tile_world"] = frame_seed, tile_size, tile_rank, tile_world
-        p["flags"] = (FLAG_COUNTERS if counters else 0) | (FLAG_NO_SHADOWS if no_shadows else 0) | (FLAG_KERNEL_V1 if kernel_v1 else 0)
+        p["flags"] = (FLAG_COUNTERS if counters else 0) | (FLAG_NO_SHADOWS if no_shadows else 0) | (FLAG_KERNEL_V1 if kernel_v1 else 0) | (FLAG_KERNEL_SM if kernel_sm else 0)
         self._check(self.lib.rt_render(self._h, _p(p)))
         self.width, self.height = width, height
         return self.stats()

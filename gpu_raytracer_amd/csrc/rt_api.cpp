@@ -19,6 +19,7 @@
 #include "device_layout.h"
 #include "half.h"
 #include "kernels.h"
+#include "wavefront.h"
 
 namespace {
 
@@ -40,6 +41,10 @@ struct DeviceState {
     unsigned long long* counters = nullptr;
     uint32_t fb_w = 0, fb_h = 0;
     uint32_t tile_first = 0, tile_stride = 1, n_owned = 0; // of the last rt_render
+    rt::WfBuffers wf{};                                    // wavefront pipeline state (extended mode)
+    bool used_wavefront = false;
+    uint32_t wf_lights = 0;
+    std::vector<void*> wf_allocs;
 };
 
 } // namespace
@@ -90,6 +95,14 @@ void free_targets(DeviceState& d) {
     (void)hipFree(d.rgba32f); (void)hipFree(d.chan[0]); (void)hipFree(d.chan[1]); (void)hipFree(d.chan[2]); (void)hipFree(d.prim_id); (void)hipFree(d.hit_t);
     d.rgba32f = nullptr; d.chan[0] = d.chan[1] = d.chan[2] = nullptr; d.prim_id = nullptr; d.hit_t = nullptr;
     d.fb_w = d.fb_h = 0;
+}
+
+void free_wavefront(DeviceState& d) {
+    (void)hipSetDevice(d.device);
+    for (void* p : d.wf_allocs) (void)hipFree(p);
+    d.wf_allocs.clear();
+    d.wf = rt::WfBuffers{};
+    d.wf_lights = 0;
 }
 
 template <class T>
@@ -256,6 +269,59 @@ int upload_common(rt_ctx* ctx, const rt_sphere* spheres, uint32_t n_spheres, con
     return RT_OK;
 }
 
+// Path-state arrays and queues of the wavefront pipeline, sized for `batch` samples per owned pixel block.
+int ensure_wavefront(rt_ctx* ctx, DeviceState& d, uint32_t n_blocks, uint32_t batch, uint32_t n_lights) {
+    const uint32_t capacity = n_blocks * batch * 64u;
+    const uint32_t ovf_entries = ctx->scene_counts.stack_entries + 3u > RT_WF_LDS_STACK ? ctx->scene_counts.stack_entries + 3u - RT_WF_LDS_STACK : 1u;
+    if (d.wf.capacity >= capacity && d.wf.n_blocks == n_blocks && d.wf.batch == batch && d.wf_lights >= n_lights && d.wf.counters &&
+        d.wf.ovf_entries >= ovf_entries)
+        return RT_OK;
+    free_wavefront(d);
+    HIPCHK(ctx, hipSetDevice(d.device));
+    auto alloc = [&](void** p, size_t bytes) -> hipError_t {
+        hipError_t e = hipMalloc(p, bytes ? bytes : 16);
+        if (e == hipSuccess) d.wf_allocs.push_back(*p);
+        return e;
+    };
+    rt::WfBuffers& w = d.wf;
+    const size_t P = capacity ? capacity : 64;
+    HIPCHK(ctx, alloc((void**)&w.ray_o, P * 16));
+    HIPCHK(ctx, alloc((void**)&w.ray_d, P * 16));
+    HIPCHK(ctx, alloc((void**)&w.hit, P * 16));
+    HIPCHK(ctx, alloc((void**)&w.thr, P * 16));
+    HIPCHK(ctx, alloc((void**)&w.rad, P * 16));
+    HIPCHK(ctx, alloc((void**)&w.vtx_p, P * 16));
+    HIPCHK(ctx, alloc((void**)&w.vtx_n, P * 16));
+    HIPCHK(ctx, alloc((void**)&w.sample_rad, P * 16));
+    HIPCHK(ctx, alloc((void**)&w.vis, P * 4));
+    HIPCHK(ctx, alloc((void**)&w.pxy, P * 4));
+    HIPCHK(ctx, alloc((void**)&w.q_ext[0], P * 4));
+    HIPCHK(ctx, alloc((void**)&w.q_ext[1], P * 4));
+    HIPCHK(ctx, alloc((void**)&w.q_vtx, P * 4));
+    HIPCHK(ctx, alloc((void**)&w.q_shadow, P * 4 * (size_t)std::max(1u, n_lights)));
+    HIPCHK(ctx, alloc((void**)&w.counters, rt::WF_N_COUNTERS * sizeof(uint32_t)));
+    HIPCHK(ctx, alloc((void**)&w.totals, 8 * sizeof(unsigned long long)));
+    HIPCHK(ctx, alloc((void**)&w.accum, (size_t)std::max(1u, n_blocks) * 64 * 16));
+    HIPCHK(ctx, alloc((void**)&w.stack_ovf, (size_t)rt::wf_persistent_waves() * ovf_entries * 64 * 4));
+    w.ovf_entries = ovf_entries;
+    w.n_blocks = n_blocks;
+    w.batch = batch;
+    w.capacity = capacity;
+    d.wf_lights = n_lights;
+    return RT_OK;
+}
+
+// Samples per pixel kept in flight by the wavefront pipeline: as many as fit ~8M paths (RT_WF_BATCH overrides).
+uint32_t wavefront_batch(uint32_t n_blocks, uint32_t spp) {
+    uint32_t want = 0;
+    if (const char* e = std::getenv("RT_WF_BATCH")) want = (uint32_t)std::strtoul(e, nullptr, 10);
+    if (want == 0) {
+        const uint64_t target_paths = 8ull << 20;
+        want = (uint32_t)std::max<uint64_t>(1, target_paths / std::max<uint64_t>(1, (uint64_t)n_blocks * 64u));
+    }
+    return std::max(1u, std::min(want, spp));
+}
+
 // Launch one frame (or one explicit tile) on every device and wait.
 int run_frame(rt_ctx* ctx, DevFrame fr, bool counters, uint32_t world, uint32_t rank, bool single_tile) {
     double w0 = now_ms();
@@ -278,9 +344,35 @@ int run_frame(rt_ctx* ctx, DevFrame fr, bool counters, uint32_t world, uint32_t 
         }
         HIPCHK(ctx, hipMemsetAsync(d.counters, 0, 16 * sizeof(unsigned long long), d.stream));
         HIPCHK(ctx, hipEventRecord(d.ev0, d.stream));
-        if (f.mode == RT_MODE_EXTENDED)
+        const bool wavefront = f.mode == RT_MODE_EXTENDED && !(f.flags & (RT_FLAG_KERNEL_V1 | RT_FLAG_KERNEL_SM)) &&
+                               ctx->scene_counts.n_lights <= RT_WF_MAX_LIGHTS;
+        if (wavefront) {
+            const uint32_t n_blocks = f.n_owned_tiles * rt::blocks_per_tile(f.tile_size);
+            const uint32_t batch = wavefront_batch(n_blocks, f.spp);
+            rc = ensure_wavefront(ctx, d, n_blocks, batch, ctx->scene_counts.n_lights);
+            if (rc != RT_OK) return rc;
+            HIPCHK(ctx, hipMemsetAsync(d.wf.totals, 0, 8 * sizeof(unsigned long long), d.stream));
+            HIPCHK(ctx, hipEventRecord(d.ev0, d.stream)); // re-record: allocation above is not part of the kernel time
+            const DevScene dsc = scene_for(ctx, d);
+            for (uint32_t first = 0; first < f.spp; first += batch) {
+                const uint32_t n = std::min(batch, f.spp - first);
+                HIPCHK(ctx, rt::wf_generate(dsc, f, d.wf, first, n, d.stream));
+                for (uint32_t it = 0; it <= f.max_bounce; it++) {
+                    HIPCHK(ctx, rt::wf_bounce(dsc, f, d.wf, it, counters, d.stream));
+                    if ((it & 7u) == 7u && it < f.max_bounce) { // long paths: stop as soon as every path has ended
+                        uint32_t alive = 0;
+                        HIPCHK(ctx, hipMemcpyAsync(&alive, d.wf.counters + rt::WF_EXT_COUNT, 4, hipMemcpyDeviceToHost, d.stream));
+                        HIPCHK(ctx, hipStreamSynchronize(d.stream));
+                        if (alive == 0) break;
+                    }
+                }
+                HIPCHK(ctx, rt::wf_resolve(f, d.wf, targets_for(d), n, first == 0, first + n >= f.spp, d.stream));
+            }
+            d.used_wavefront = true;
+        } else if (f.mode == RT_MODE_EXTENDED) {
+            d.used_wavefront = false;
             HIPCHK(ctx, rt::launch_render_extended(scene_for(ctx, d), f, targets_for(d), counters, d.stream));
-        else
+        } else
             HIPCHK(ctx, rt::launch_render_reference(scene_for(ctx, d), f, targets_for(d), counters, d.stream));
         HIPCHK(ctx, hipEventRecord(d.ev1, d.stream));
     }
@@ -295,7 +387,19 @@ int run_frame(rt_ctx* ctx, DevFrame fr, bool counters, uint32_t world, uint32_t 
         float ms = 0.0f;
         HIPCHK(ctx, hipEventElapsedTime(&ms, d.ev0, d.ev1));
         kernel_ms = std::max(kernel_ms, (double)ms);
-        if (counters || extended) {
+        if (extended && d.used_wavefront) {
+            unsigned long long t[8];
+            HIPCHK(ctx, hipMemcpy(t, d.wf.totals, sizeof t, hipMemcpyDeviceToHost));
+            cnt[0] += t[0] + t[1] + t[2];
+            cnt[3] += t[0];
+            cnt[4] += t[1];
+            cnt[5] += t[2];
+            cnt[1] += t[3];
+            cnt[2] += t[4];
+            cnt[8] = std::max(cnt[8], t[5]); // diagnostics: stack high-water mark, visits with > 16 / > 24 entries
+            cnt[9] += t[6];
+            cnt[10] += t[7];
+        } else if (counters || extended) {
             unsigned long long c[16];
             HIPCHK(ctx, hipMemcpy(c, d.counters, sizeof c, hipMemcpyDeviceToHost));
             for (int k = 0; k < 16; k++) cnt[k] += c[k];
@@ -383,6 +487,7 @@ void rt_destroy(rt_ctx* ctx) {
         if (d.stream) (void)hipStreamSynchronize(d.stream);
         free_scene(d);
         free_targets(d);
+        free_wavefront(d);
         (void)hipFree(d.counters);
         if (d.ev0) (void)hipEventDestroy(d.ev0);
         if (d.ev1) (void)hipEventDestroy(d.ev1);

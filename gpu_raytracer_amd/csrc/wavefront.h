@@ -1,0 +1,65 @@
+// wavefront.h — the queue-based ("wavefront") pipeline of the extended mode.
+//
+// The reference declares a wavefront path tracer (WavefrontRay / WavefrontCounters, shared/src/lib.rs:165-194,
+// host loop src/compute.rs:413-479) but implements neither queues nor continuation rays.  This is that design
+// built for MI355X: path state and ray queues live in HBM (288 GB makes millions of paths in flight cheap),
+// each stage is its own kernel so every wave runs ONE code path, queue slots are handed out with
+// wave-aggregated atomics (ballot + prefix count), and the two traversal stages are persistent kernels whose
+// idle lanes refill themselves from the queue.
+#ifndef RT_WAVEFRONT_H
+#define RT_WAVEFRONT_H
+
+#include <hip/hip_runtime.h>
+
+#include "device_layout.h"
+
+namespace rt {
+
+// counters[] slots (device memory, uint32)
+enum WfCounter : uint32_t {
+    WF_EXT_COUNT = 0,    // entries in the current extension queue
+    WF_EXT_NEXT = 1,     // entries appended to the next extension queue
+    WF_VTX_COUNT = 2,    // vertices awaiting wf_finish
+    WF_SHADOW_COUNT = 3, // shadow segments of this iteration
+    WF_EXT_CURSOR = 4,   // persistent-kernel fetch cursors
+    WF_SHADOW_CURSOR = 5,
+    WF_N_COUNTERS = 8
+};
+
+struct WfBuffers {
+    // per path slot (P = samples_in_batch * n_blocks * 64)
+    float4* ray_o;       // xyz origin
+    float4* ray_d;       // xyz direction (also the incoming direction of the current vertex)
+    uint4* hit;          // x = t bits, y = primitive id, z = triangle slot / sphere index
+    float4* thr;         // xyz throughput, w = bits: hero channel | depth << 8
+    float4* rad;         // xyz radiance of the sample so far, w = bits: rng state
+    float4* vtx_p;       // xyz vertex position, w = bits: material id
+    float4* vtx_n;       // xyz geometric normal
+    float4* sample_rad;  // xyz final radiance of the sample (written when the path ends)
+    uint32_t* vis;       // bit li set: light li is visible from the current vertex
+    uint32_t* pxy;       // x | y << 16, 0xFFFFFFFF = no pixel (tile edge)
+    // queues
+    uint32_t* q_ext[2];  // path ids to extend (double buffered)
+    uint32_t* q_vtx;     // path ids with a vertex awaiting its shadow results
+    uint32_t* q_shadow;  // path id | light << 27
+    uint32_t* counters;  // WfCounter
+    unsigned long long* totals; // [0] camera [1] continuation [2] shadow segments, [3] node visits, [4] triangle tests
+    float4* accum;       // per owned pixel slot: running sum over samples (in sample order)
+    uint32_t* stack_ovf; // global overflow part of the traversal stacks: [persistent wave][entry][lane]
+    uint32_t ovf_entries; // entries per lane in it
+    uint32_t n_blocks;   // 8x8 pixel blocks owned by this device
+    uint32_t batch;      // samples per pixel in flight
+    uint32_t capacity;   // path slots
+};
+
+#define RT_WF_LDS_STACK 16 /* traversal stack entries kept in LDS by the persistent kernels; deeper ones overflow to HBM */
+#define RT_WF_MAX_LIGHTS 32u /* visibility is one bit per light in a 32-bit word */
+#define RT_WF_ID_MASK 0x07FFFFFFu
+
+uint32_t wf_persistent_waves(); // grid size (in 64-lane blocks) of the persistent traversal kernels on the current device
+hipError_t wf_generate(const DevScene& sc, const DevFrame& fr, const WfBuffers& wb, uint32_t first_sample, uint32_t n_samples, hipStream_t s);
+hipError_t wf_bounce(const DevScene& sc, const DevFrame& fr, const WfBuffers& wb, uint32_t iteration, bool counters, hipStream_t s);
+hipError_t wf_resolve(const DevFrame& fr, const WfBuffers& wb, const DevTargets& tg, uint32_t n_samples, bool first_batch, bool last_batch, hipStream_t s);
+
+} // namespace rt
+#endif

@@ -1,0 +1,495 @@
+// wavefront.hip — queue-based pipeline of the extended mode (see wavefront.h).
+//
+// Stages per bounce iteration (each a kernel, one code path per wave):
+//   k_wf_trace<closest>  persistent; lanes pull path ids from the extension queue, walk the BVH, store the hit
+//   k_wf_shade           consume the hit: miss / invalid material end the path; otherwise store the vertex and
+//                        enqueue one shadow segment per light with a non-zero contribution
+//   k_wf_trace<any hit>  persistent; shadow segments set a visibility bit per (path, light)
+//   k_wf_finish          sum the visible contributions IN LIGHT ORDER, add emission, then terminal shading or
+//                        continuation sampling + russian roulette; survivors go to the next extension queue
+//   k_wf_advance         one thread: totals += queue sizes, swap queues, reset cursors
+// Per-path arithmetic and its order are exactly those of the CPU statement (and of the megakernels in
+// kernels.hip); queues only change WHEN a path's next step runs, so images stay bit-identical.
+#include "wavefront.h"
+
+#include "device_common.h"
+
+using namespace rtdev;
+
+#ifndef RT_WF_REFILL
+#define RT_WF_REFILL 16 /* idle lanes in a wave before it fetches new segments */
+#endif
+#ifndef RT_WF_CHUNK
+#define RT_WF_CHUNK 256 /* queue entries a wave claims per atomic */
+#endif
+#ifndef RT_WF_LEAF_THRESHOLD
+#define RT_WF_LEAF_THRESHOLD 24 /* lanes holding a postponed leaf before the triangle tests run */
+#endif
+#ifndef RT_WF_WAVES_PER_CU
+#define RT_WF_WAVES_PER_CU 24
+#endif
+#define WF_REF_NONE RT_DEV_LEAF_FLAG /* empty leaf reference: nothing left to visit */
+
+namespace {
+
+__device__ __forceinline__ V3 f4v(float4 a) { return v3(a.x, a.y, a.z); }
+
+// ---------------------------------------------------------------------------------------------------------
+// generation: one lane per path slot (sample k of pixel (block b, lane l))
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WAVE) void k_wf_generate(DevFrame fr, rt::WfBuffers wb, uint32_t first_sample) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t k = blockIdx.x / wb.n_blocks, b = blockIdx.x - k * wb.n_blocks;
+    const PixelCoord px = block_pixel_at(fr, b, lane);
+    const uint32_t p = blockIdx.x * WAVE + lane;
+    if (px.valid) {
+        SimpleRng rng = rng_for(fr.frame_seed + px.x + px.y * fr.width, first_sample + k);
+        float jx = 0.5f, jy = 0.5f;
+        if (fr.spp > 1) {
+            jx = rng.next_f32();
+            jy = rng.next_f32();
+        }
+        V3 o, d;
+        camera_ray(fr.cam, (float)px.x + jx, (float)px.y + jy, true, o, d);
+        wb.ray_o[p] = make_float4(o.x, o.y, o.z, 0.0f);
+        wb.ray_d[p] = make_float4(d.x, d.y, d.z, 0.0f);
+        wb.thr[p] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(3u)); // channel 3 (none), depth 0
+        wb.rad[p] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(rng.seed));
+        wb.pxy[p] = px.x | (px.y << 16);
+    } else {
+        wb.pxy[p] = 0xFFFFFFFFu;
+        wb.sample_rad[p] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    wave_append(wb.q_ext[0], &wb.counters[rt::WF_EXT_COUNT], px.valid, p);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// persistent traversal kernel (closest hit for extension segments, any hit for shadow segments)
+// ---------------------------------------------------------------------------------------------------------
+template <bool COUNT, bool ANY>
+__global__ __launch_bounds__(WAVE) void k_wf_trace(DevScene sc, rt::WfBuffers wb, const uint32_t* __restrict__ queue, uint32_t count_slot,
+                                                   uint32_t cursor_slot) {
+    extern __shared__ uint32_t s_stack[];
+    const uint32_t lane = threadIdx.x;
+    uint32_t* __restrict__ stack = s_stack + lane;
+    uint32_t* __restrict__ ovf = wb.stack_ovf + (size_t)blockIdx.x * wb.ovf_entries * WAVE + lane;
+    const uint4* __restrict__ nodes = reinterpret_cast<const uint4*>(sc.nodes);
+    const uint32_t count = wb.counters[count_slot];
+    uint32_t* cursor = &wb.counters[cursor_slot];
+    Counts cnt = {0u, 0u};
+    int sp_max = 0;
+    uint32_t sp_gt16 = 0, sp_gt24 = 0;
+
+    bool active = false, exhausted = false;
+    uint32_t chunk_next = 0, chunk_end = 0; // wave-uniform
+    uint32_t id = 0, li = 0;
+    V3 o = v3(0.0f, 0.0f, 0.0f), d = o;
+    FilterRay fray;
+    fray.o = o;
+    fray.inv = o;
+    Hit hit;
+    hit.t = RT_F32_MAX;
+    hit.prim = RT_PRIM_MISS;
+    hit.slot = 0;
+    uint32_t cur = WF_REF_NONE, pleaf = WF_REF_NONE;
+    int sp = 0;
+
+    for (;;) {
+        // ---- refill: idle lanes take the next queue entries.  The wave owns a private chunk [chunk_next, chunk_end)
+        // of the queue and only touches the global cursor when it runs dry: a single counter sustains ~90 M
+        // atomics/s, far less than thousands of waves refilling 16 lanes at a time would ask of it.
+        const unsigned long long idle = __ballot(!active);
+        if (!exhausted && (__popcll(idle) >= RT_WF_REFILL || idle == ~0ull)) {
+            if (chunk_next >= chunk_end) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(cursor, (uint32_t)RT_WF_CHUNK);
+                base = __shfl(base, 0, WAVE);
+                chunk_next = base;
+                chunk_end = min(base + (uint32_t)RT_WF_CHUNK, count);
+                if (base >= count) exhausted = true;
+            }
+            if (!exhausted) {
+                const uint32_t idx = chunk_next + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                chunk_next += (uint32_t)__popcll(idle);
+                if (!active && idx < chunk_end) {
+                    const uint32_t e = queue[idx];
+                    if (ANY) {
+                        id = e & RT_WF_ID_MASK;
+                        li = e >> 27;
+                        const V3 point = f4v(wb.vtx_p[id]), normal = f4v(wb.vtx_n[id]);
+                        float dist;
+                        shadow_segment(sc.lights[li], point, d, dist);
+                        o = point + normal * EXT_EPS;
+                        hit.t = dist;
+                    } else {
+                        id = e;
+                        o = f4v(wb.ray_o[id]);
+                        d = f4v(wb.ray_d[id]);
+                        hit.t = RT_F32_MAX;
+                    }
+                    hit.prim = RT_PRIM_MISS;
+                    hit.slot = 0;
+                    fray = make_filter_ray(o, d);
+                    test_spheres(sc, o, d, hit);
+                    sp = 0;
+                    cur = sc.n_tris ? sc.root_ref : WF_REF_NONE;
+                    pleaf = WF_REF_NONE;
+                    active = true;
+                    if (ANY && hit.prim != RT_PRIM_MISS) cur = WF_REF_NONE; // occluded by a sphere already
+                }
+            }
+        }
+        if (__ballot(active) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+        // ---- traversal steps until enough lanes have finished ----
+        for (;;) {
+            if (active && (cur & RT_DEV_LEAF_FLAG) && cur != WF_REF_NONE && pleaf == WF_REF_NONE) {
+                pleaf = cur; // postpone the leaf, keep descending
+                if (sp > 0) {
+                    sp--;
+                    cur = stack_load<RT_WF_LDS_STACK>(stack, ovf, sp);
+                } else {
+                    cur = WF_REF_NONE;
+                }
+            }
+            const bool can_node = active && !(cur & RT_DEV_LEAF_FLAG);
+            const bool has_leaf = active && pleaf != WF_REF_NONE;
+            const unsigned long long m_node = __ballot(can_node), m_leaf = __ballot(has_leaf);
+            if (m_node != 0ull && __popcll(m_leaf) < RT_WF_LEAF_THRESHOLD) {
+                if (can_node) {
+                    if (!visit_node4<COUNT, RT_WF_LDS_STACK>(nodes, sc.stack_entries, fray, hit.t, stack, sp, cur, cnt, ovf)) cur = WF_REF_NONE;
+                    if (COUNT) {
+                        sp_max = max(sp_max, sp);
+                        sp_gt16 += sp > 16 ? 1u : 0u;
+                        sp_gt24 += sp > 24 ? 1u : 0u;
+                    }
+                }
+            } else if (m_leaf != 0ull) {
+                if (has_leaf) {
+                    const uint32_t start = pleaf & RT_DEV_LEAF_START_MASK, n_tri = (pleaf >> RT_DEV_LEAF_COUNT_SHIFT) & 0xFu;
+                    pleaf = WF_REF_NONE;
+                    for (uint32_t i = 0; i < n_tri; i++) {
+                        if (COUNT) cnt.tris++;
+                        test_triangle(sc.tris, start + i, o, d, hit);
+                        if (ANY && hit.prim != RT_PRIM_MISS) break;
+                    }
+                    if (ANY && hit.prim != RT_PRIM_MISS) cur = WF_REF_NONE; // occluded: nothing more to do
+                }
+            }
+            if (active && cur == WF_REF_NONE && pleaf == WF_REF_NONE) { // segment finished
+                if (ANY) {
+                    if (hit.prim == RT_PRIM_MISS) atomicOr(&wb.vis[id], 1u << li);
+                } else {
+                    wb.hit[id] = make_uint4(__float_as_uint(hit.t), hit.prim, hit.slot, 0u);
+                }
+                active = false;
+            }
+            const unsigned long long still = __ballot(active);
+            if (still == 0ull) break;
+            if (!exhausted && __popcll(~still) >= RT_WF_REFILL) break;
+        }
+    }
+    if (COUNT) {
+        unsigned long long n0 = wave_sum(cnt.nodes), n1 = wave_sum(cnt.tris);
+        unsigned long long g16 = wave_sum(sp_gt16), g24 = wave_sum(sp_gt24);
+        for (int off = 32; off > 0; off >>= 1) sp_max = max(sp_max, __shfl_down(sp_max, off, WAVE));
+        if (lane == 0) {
+            atomicAdd(&wb.totals[3], n0);
+            atomicAdd(&wb.totals[4], n1);
+            atomicMax(&wb.totals[5], (unsigned long long)sp_max);
+            atomicAdd(&wb.totals[6], g16);
+            atomicAdd(&wb.totals[7], g24);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// shading stage 1: consume the closest hit, store the vertex, enqueue shadow segments
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wf_end_path(const rt::WfBuffers& wb, uint32_t id, V3 radiance) {
+    wb.sample_rad[id] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+}
+
+__global__ __launch_bounds__(256) void k_wf_shade(DevScene sc, DevFrame fr, rt::WfBuffers wb, const uint32_t* __restrict__ queue) {
+    const uint32_t count = wb.counters[rt::WF_EXT_COUNT];
+    const bool shadows = (fr.flags & 2u) == 0;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    // every wave runs the same number of iterations so the wave-aggregated appends see whole waves
+    for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += stride) {
+        const uint32_t i = base + threadIdx.x;
+        const bool have = i < count;
+        uint32_t id = 0;
+        bool vertex = false;
+        V3 point = v3(0, 0, 0), normal = point;
+        uint32_t material_id = 0;
+        if (have) {
+            id = queue[i];
+            const uint4 h = wb.hit[id];
+            const float4 th = wb.thr[id], ra = wb.rad[id];
+            const V3 throughput = f4v(th);
+            V3 radiance = f4v(ra);
+            if (h.y == RT_PRIM_MISS) { // process_wavefront_ray, wavefront.rs:146-151
+                radiance = radiance + v3(0.1f, 0.2f, 0.3f) * throughput;
+                wf_end_path(wb, id, radiance);
+            } else {
+                Hit hit;
+                hit.t = __uint_as_float(h.x);
+                hit.prim = h.y;
+                hit.slot = h.z;
+                hit_geometry(sc, hit, f4v(wb.ray_o[id]), f4v(wb.ray_d[id]), point, normal, material_id);
+                if (material_id >= sc.n_materials) {
+                    radiance = radiance + v3(1.0f, 0.0f, 1.0f) * throughput;
+                    wf_end_path(wb, id, radiance);
+                } else {
+                    vertex = true;
+                    wb.vtx_p[id] = make_float4(point.x, point.y, point.z, __uint_as_float(material_id));
+                    wb.vtx_n[id] = make_float4(normal.x, normal.y, normal.z, 0.0f);
+                    wb.vis[id] = 0u;
+                }
+            }
+        }
+        if (have && !vertex) wb.vtx_p[id] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu)); // "no vertex": k_wf_finish skips it
+        if (shadows) {
+            // which lights need a shadow segment (non-zero contribution)?  One bit per light, then ONE
+            // aggregated append per wave: exclusive scan of the per-lane counts + a single atomicAdd.
+            uint32_t mask = 0;
+            if (vertex) {
+                const DevMaterial m = sc.materials[material_id];
+                for (uint32_t li = 0; li < sc.n_lights; li++) {
+                    V3 sdir;
+                    float sdist;
+                    const V3 contrib = light_contribution(sc.lights[li], m, point, normal, sdir, sdist);
+                    if (contrib.x != 0.0f || contrib.y != 0.0f || contrib.z != 0.0f) mask |= 1u << li;
+                }
+            }
+            const uint32_t mine = (uint32_t)__popc(mask);
+            uint32_t incl = mine;
+            const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+            for (int off = 1; off < WAVE; off <<= 1) {
+                const uint32_t v = __shfl_up(incl, off, WAVE);
+                if ((int)lane >= off) incl += v;
+            }
+            const uint32_t total = __shfl(incl, WAVE - 1, WAVE);
+            if (total) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&wb.counters[rt::WF_SHADOW_COUNT], total);
+                base = __shfl(base, 0, WAVE);
+                uint32_t at = base + incl - mine;
+                while (mask) {
+                    const uint32_t li = (uint32_t)__ffs((int)mask) - 1u;
+                    mask &= mask - 1u;
+                    wb.q_shadow[at++] = id | (li << 27);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// shading stage 2: ordered light sum, terminal shading or continuation
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_wf_finish(DevScene sc, DevFrame fr, rt::WfBuffers wb, const uint32_t* __restrict__ queue,
+                                                  uint32_t* __restrict__ next_queue) {
+    const uint32_t count = wb.counters[rt::WF_EXT_COUNT];
+    const bool shadows = (fr.flags & 2u) == 0;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += stride) {
+        const uint32_t i = base + threadIdx.x;
+        bool cont = false;
+        uint32_t id = 0;
+        float4 vp = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
+        if (i < count) {
+            id = queue[i];
+            vp = wb.vtx_p[id];
+        }
+        if (__float_as_uint(vp.w) != 0xFFFFFFFFu) { // paths that ended in k_wf_shade carry the "no vertex" marker
+
+            const V3 point = f4v(vp), normal = f4v(wb.vtx_n[id]);
+            const uint32_t material_id = __float_as_uint(vp.w);
+            const DevMaterial m = sc.materials[material_id];
+            const float4 th = wb.thr[id], ra = wb.rad[id];
+            V3 throughput = f4v(th), radiance = f4v(ra);
+            const uint32_t tw = __float_as_uint(th.w);
+            uint32_t channel = tw & 0xFFu;
+            const uint32_t depth = tw >> 8;
+            SimpleRng rng = {__float_as_uint(ra.w)};
+            const uint32_t vis = wb.vis[id];
+            const bool terminal = depth >= fr.max_bounce;
+            // direct light: the reference's loop order (lighting.rs:33-43), occluded lights skipped
+            V3 lighting = v3(0.0f, 0.0f, 0.0f);
+            if (terminal) lighting = lighting + ld3(m.albedo) * 0.1f;
+            for (uint32_t li = 0; li < sc.n_lights; li++) {
+                V3 sdir;
+                float sdist;
+                const V3 contrib = light_contribution(sc.lights[li], m, point, normal, sdir, sdist);
+                const bool nonzero = contrib.x != 0.0f || contrib.y != 0.0f || contrib.z != 0.0f;
+                if (nonzero && shadows && !((vis >> li) & 1u)) continue;
+                lighting = lighting + contrib;
+            }
+            lighting = lighting + ld3(m.emission);
+            const float tf = fminf(fmaxf(m.transmission, 0.0f), 1.0f);
+            if (terminal) {
+                V3 out = lighting;
+                if (tf > 0.0f) out = transmission_mix(m, lighting, tf);
+                radiance = radiance + out * throughput;
+                wf_end_path(wb, id, radiance);
+            } else {
+                radiance = radiance + (lighting * (1.0f - tf)) * throughput;
+                const V3 din = f4v(wb.ray_d[id]);
+                const bool front = dot(normal, din) < 0.0f;
+                const V3 nf = front ? normal : -normal;
+                bool transmit = false;
+                if (tf > 0.0f) transmit = rng.next_f32() < tf;
+                V3 ndir, norigin;
+                const V3 albedo = ld3(m.albedo);
+                bool absorbed = false;
+                if (transmit) {
+                    if (channel == 3) {
+                        uint32_t c = (uint32_t)(rng.next_f32() * 3.0f);
+                        channel = c < 2 ? c : 2;
+                        throughput = v3(channel == 0 ? throughput.x * 3.0f : 0.0f, channel == 1 ? throughput.y * 3.0f : 0.0f,
+                                        channel == 2 ? throughput.z * 3.0f : 0.0f);
+                    }
+                    const float offs = channel == 0 ? -0.018f : (channel == 1 ? 0.0f : 0.035f);
+                    const float ior_c = m.ior + offs;
+                    const float eta = front ? (1.0f / ior_c) : ior_c;
+                    const float cos_i = -dot(nf, din);
+                    const float sin2_t = eta * eta * (1.0f - cos_i * cos_i);
+                    if (sin2_t > 1.0f) {
+                        ndir = din - nf * (2.0f * dot(din, nf));
+                        norigin = point + nf * EXT_EPS;
+                    } else {
+                        const float cos_t = sqrtf(1.0f - sin2_t);
+                        ndir = din * eta + nf * (eta * cos_i - cos_t);
+                        norigin = point - nf * EXT_EPS;
+                    }
+                    ndir = normalize(ndir);
+                    throughput = throughput * albedo;
+                } else if (m.metallic > 0.5f) {
+                    const float u1 = rng.next_f32(), u2 = rng.next_f32();
+                    const V3 r = din - nf * (2.0f * dot(din, nf));
+                    ndir = normalize(r + unit_vector(u1, u2) * m.roughness);
+                    absorbed = !(dot(ndir, nf) > 0.0f);
+                    norigin = point + nf * EXT_EPS;
+                    if (!absorbed) throughput = throughput * albedo;
+                } else {
+                    const float u1 = rng.next_f32(), u2 = rng.next_f32();
+                    V3 w = nf + unit_vector(u1, u2);
+                    if (dot(w, w) < 1e-12f) w = nf;
+                    ndir = normalize(w);
+                    norigin = point + nf * EXT_EPS;
+                    throughput = throughput * albedo;
+                }
+                if (!absorbed && depth >= 2) {
+                    const float p = fminf(fmaxf(fmaxf(fmaxf(throughput.x, throughput.y), throughput.z), 0.05f), 1.0f);
+                    if (rng.next_f32() > p) absorbed = true;
+                    else throughput = v3(throughput.x / p, throughput.y / p, throughput.z / p);
+                }
+                if (absorbed) {
+                    wf_end_path(wb, id, radiance);
+                } else {
+                    cont = true;
+                    wb.ray_o[id] = make_float4(norigin.x, norigin.y, norigin.z, 0.0f);
+                    wb.ray_d[id] = make_float4(ndir.x, ndir.y, ndir.z, 0.0f);
+                    wb.thr[id] = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(channel | ((depth + 1u) << 8)));
+                    wb.rad[id] = make_float4(radiance.x, radiance.y, radiance.z, __uint_as_float(rng.seed));
+                }
+            }
+        }
+        wave_append(next_queue, &wb.counters[rt::WF_EXT_NEXT], cont, id);
+    }
+}
+
+__global__ void k_wf_advance(rt::WfBuffers wb, uint32_t iteration) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t* c = wb.counters;
+    wb.totals[iteration == 0 ? 0 : 1] += c[rt::WF_EXT_COUNT];
+    wb.totals[2] += c[rt::WF_SHADOW_COUNT];
+    c[rt::WF_EXT_COUNT] = c[rt::WF_EXT_NEXT];
+    c[rt::WF_EXT_NEXT] = 0;
+    c[rt::WF_VTX_COUNT] = 0;
+    c[rt::WF_SHADOW_COUNT] = 0;
+    c[rt::WF_EXT_CURSOR] = 0;
+    c[rt::WF_SHADOW_CURSOR] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// resolve: add the batch's samples to each pixel's running sum IN SAMPLE ORDER; write the image on the last batch
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WAVE) void k_wf_resolve(DevFrame fr, rt::WfBuffers wb, DevTargets tg, uint32_t n_samples, uint32_t first_batch,
+                                                     uint32_t last_batch) {
+    const uint32_t lane = threadIdx.x, b = blockIdx.x;
+    const uint32_t q = b * WAVE + lane;
+    float4 acc = first_batch ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : wb.accum[q];
+    V3 sum = f4v(acc);
+    for (uint32_t k = 0; k < n_samples; k++) sum = sum + f4v(wb.sample_rad[(size_t)(k * wb.n_blocks + b) * WAVE + lane]);
+    wb.accum[q] = make_float4(sum.x, sum.y, sum.z, 0.0f);
+    if (!last_batch) return;
+    const PixelCoord px = block_pixel_at(fr, b, lane);
+    if (!px.valid) return;
+    const float n = (float)fr.spp;
+    const V3 color = v3(sum.x / n, sum.y / n, sum.z / n);
+    const size_t pix = (size_t)px.y * fr.width + px.x;
+    if (tg.rgba32f) reinterpret_cast<float4*>(tg.rgba32f)[pix] = make_float4(color.x, color.y, color.z, 1.0f);
+    if (tg.chan[0]) reinterpret_cast<uint32_t*>(tg.chan[0])[pix] = unorm8(color.x) | 0xFF000000u;
+    if (tg.chan[1]) reinterpret_cast<uint32_t*>(tg.chan[1])[pix] = (unorm8(color.y) << 8) | 0xFF000000u;
+    if (tg.chan[2]) reinterpret_cast<uint32_t*>(tg.chan[2])[pix] = (unorm8(color.z) << 16) | 0xFF000000u;
+}
+
+int g_cu_count = 0;
+int cu_count() {
+    if (g_cu_count == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_cu_count = prop.multiProcessorCount;
+        if (g_cu_count <= 0) g_cu_count = 256;
+    }
+    return g_cu_count;
+}
+
+} // namespace
+
+namespace rt {
+
+uint32_t wf_persistent_waves() { return (uint32_t)(cu_count() * RT_WF_WAVES_PER_CU); }
+
+hipError_t wf_generate(const DevScene&, const DevFrame& fr, const WfBuffers& wb, uint32_t first_sample, uint32_t n_samples, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(wb.counters, 0, WF_N_COUNTERS * sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    if (wb.n_blocks == 0 || n_samples == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_wf_generate, dim3(n_samples * wb.n_blocks), dim3(WAVE), 0, s, fr, wb, first_sample);
+    return hipGetLastError();
+}
+
+hipError_t wf_bounce(const DevScene& sc, const DevFrame& fr, const WfBuffers& wb, uint32_t iteration, bool counters, hipStream_t s) {
+    const size_t lds = (size_t)RT_WF_LDS_STACK * WAVE * sizeof(uint32_t);
+    const dim3 pgrid(wf_persistent_waves()), pblock(WAVE);
+    const dim3 sgrid((unsigned)(cu_count() * 8)), sblock(256);
+    uint32_t* cur_q = wb.q_ext[iteration & 1u];
+    uint32_t* next_q = wb.q_ext[(iteration + 1u) & 1u];
+    if (counters)
+        hipLaunchKernelGGL((k_wf_trace<true, false>), pgrid, pblock, lds, s, sc, wb, (const uint32_t*)cur_q, (uint32_t)WF_EXT_COUNT, (uint32_t)WF_EXT_CURSOR);
+    else
+        hipLaunchKernelGGL((k_wf_trace<false, false>), pgrid, pblock, lds, s, sc, wb, (const uint32_t*)cur_q, (uint32_t)WF_EXT_COUNT, (uint32_t)WF_EXT_CURSOR);
+    hipLaunchKernelGGL(k_wf_shade, sgrid, sblock, 0, s, sc, fr, wb, (const uint32_t*)cur_q);
+    if ((fr.flags & 2u) == 0) {
+        if (counters)
+            hipLaunchKernelGGL((k_wf_trace<true, true>), pgrid, pblock, lds, s, sc, wb, (const uint32_t*)wb.q_shadow, (uint32_t)WF_SHADOW_COUNT, (uint32_t)WF_SHADOW_CURSOR);
+        else
+            hipLaunchKernelGGL((k_wf_trace<false, true>), pgrid, pblock, lds, s, sc, wb, (const uint32_t*)wb.q_shadow, (uint32_t)WF_SHADOW_COUNT, (uint32_t)WF_SHADOW_CURSOR);
+    }
+    hipLaunchKernelGGL(k_wf_finish, sgrid, sblock, 0, s, sc, fr, wb, (const uint32_t*)cur_q, next_q);
+    hipLaunchKernelGGL(k_wf_advance, dim3(1), dim3(1), 0, s, wb, iteration);
+    return hipGetLastError();
+}
+
+hipError_t wf_resolve(const DevFrame& fr, const WfBuffers& wb, const DevTargets& tg, uint32_t n_samples, bool first_batch, bool last_batch, hipStream_t s) {
+    if (wb.n_blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_wf_resolve, dim3(wb.n_blocks), dim3(WAVE), 0, s, fr, wb, tg, n_samples, first_batch ? 1u : 0u, last_batch ? 1u : 0u);
+    return hipGetLastError();
+}
+
+} // namespace rt

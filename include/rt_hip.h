@@ -53,8 +53,9 @@ extern "C" {
 #define RT_FLAG_COUNTERS 1u   /* run the counting variant of the kernel: fills node_visits / tri_tests  */
 #define RT_FLAG_NO_SHADOWS 2u /* extended mode only: lights are not gated by shadow rays (as in the     */
                               /* reference, which never traces them)                                    */
-#define RT_FLAG_KERNEL_V1 4u  /* extended mode only: run the nested-loop v1 kernel instead of the       */
-                              /* state-machine kernel (A/B measurements; same results)                  */
+#define RT_FLAG_KERNEL_V1 4u  /* extended mode only: run the nested-loop megakernel (v1) instead of the   */
+                              /* wavefront pipeline (A/B measurements; same results)                    */
+#define RT_FLAG_KERNEL_SM 8u  /* extended mode only: run the state-machine megakernel (v2) instead      */
 
 typedef struct rt_ctx rt_ctx;
 

@@ -13,6 +13,9 @@ from gpu_raytracer_amd import scenes
 pytestmark = pytest.mark.gpu
 
 
+KERNELS = {"wavefront": {}, "state_machine": {"kernel_sm": True}, "nested": {"kernel_v1": True}}
+
+
 def _gpu_ext(ctx, scene, w, h, spp, bounces, **kw):
     ctx.upload_scene(scene)
     st = ctx.render(w, h, kw.pop("camera", scene.camera), mode=2, spp=spp, max_bounces=bounces, **kw)
@@ -29,22 +32,26 @@ def test_extended_reduces_to_mode1_on_gpu(gpu_ctx, name):
     assert st["rays"] == st["primary_rays"] == 160 * 96 and st["shadow_rays"] == 0
 
 
+@pytest.mark.parametrize("kernel", list(KERNELS))
 @pytest.mark.parametrize("name,w,h,spp,bounces", [
     ("default", 96, 64, 8, 4), ("cornell12", 64, 64, 16, 4), ("cornell12", 40, 40, 3, 1), ("single_triangle", 64, 40, 4, 2)])
-def test_extended_bit_exact_vs_cpu_statement(gpu_ctx, oracle_mod, name, w, h, spp, bounces):
+def test_extended_bit_exact_vs_cpu_statement(gpu_ctx, oracle_mod, name, w, h, spp, bounces, kernel):
+    """All three device implementations (wavefront pipeline = default, state-machine megakernel, nested-loop
+    megakernel) against the CPU statement: identical segment counts and identical bits."""
     scene = scenes.SCENES[name]()
     ref = oracle_mod.render_extended(oracle_mod.PackedScene(scene, use_bvh=False), w, h, spp, bounces)
-    rgb, st = _gpu_ext(gpu_ctx, scene, w, h, spp, bounces)
+    rgb, st = _gpu_ext(gpu_ctx, scene, w, h, spp, bounces, **KERNELS[kernel])
     seg = ref["segments"]
     assert (st["primary_rays"], st["continuation_rays"], st["shadow_rays"]) == (seg["camera"], seg["continuation"], seg["shadow"])
     assert st["rays"] == seg["camera"] + seg["continuation"] + seg["shadow"]
     np.testing.assert_array_equal(rgb.view(np.uint32), ref["rgb"].view(np.uint32))
 
 
-def test_extended_soup_with_spheres_glass_metal(gpu_ctx, oracle_mod):
+@pytest.mark.parametrize("kernel", list(KERNELS))
+def test_extended_soup_with_spheres_glass_metal(gpu_ctx, oracle_mod, kernel):
     scene = scenes.random_soup(400, seed=21, size=0.7, n_spheres=3, n_lights=3)  # materials: metal, glass, emissive, diffuse
     ref = oracle_mod.render_extended(oracle_mod.PackedScene(scene, use_bvh=False), 72, 48, 6, 5, frame_seed=77)
-    rgb, st = _gpu_ext(gpu_ctx, scene, 72, 48, 6, 5, frame_seed=77)
+    rgb, st = _gpu_ext(gpu_ctx, scene, 72, 48, 6, 5, frame_seed=77, **KERNELS[kernel])
     d = np.abs(rgb - ref["rgb"]).max(-1)
     assert (d > 2e-3).mean() <= 1e-3
     np.testing.assert_array_equal(rgb.view(np.uint32), ref["rgb"].view(np.uint32))
@@ -86,3 +93,7 @@ def test_extended_full_size_properties(gpu_ctx):
     gpu_ctx.render(w, h, scene.camera, mode=2, spp=16, max_bounces=4)
     b = gpu_ctx.read_rgb32f()
     assert abs(a.mean() - b.mean()) < 0.02 * b.mean()
+    # the megakernels produce the very same image as the wavefront pipeline
+    for kw in ({"kernel_sm": True}, {"kernel_v1": True}):
+        gpu_ctx.render(w, h, scene.camera, mode=2, spp=4, max_bounces=4, **kw)
+        np.testing.assert_array_equal(gpu_ctx.read_rgb32f().view(np.uint32), a.view(np.uint32))
