@@ -295,10 +295,14 @@ int ensure_wavefront(rt_ctx* ctx, DeviceState& d, uint32_t n_blocks, uint32_t ba
     HIPCHK(ctx, alloc((void**)&w.sample_rad, P * 16));
     HIPCHK(ctx, alloc((void**)&w.vis, P * 4));
     HIPCHK(ctx, alloc((void**)&w.pxy, P * 4));
-    HIPCHK(ctx, alloc((void**)&w.q_ext[0], P * 4));
-    HIPCHK(ctx, alloc((void**)&w.q_ext[1], P * 4));
-    HIPCHK(ctx, alloc((void**)&w.q_vtx, P * 4));
-    HIPCHK(ctx, alloc((void**)&w.q_shadow, P * 4 * (size_t)std::max(1u, n_lights)));
+    // producers reserve queue space in windows (wavefront.hip): room for every real entry plus one partly used
+    // window per producing wave (4 waves per block, cu_count * 8 blocks) and the round-up of the last window
+    const size_t producer_waves = (size_t)rt::wf_shading_blocks() * 4;
+    const size_t pad_ext = (producer_waves + 1) * rt::wf_window(1), pad_shadow = (producer_waves + 1) * rt::wf_window(std::max(1u, n_lights));
+    HIPCHK(ctx, alloc((void**)&w.q_ext[0], (P + pad_ext) * 4));
+    HIPCHK(ctx, alloc((void**)&w.q_ext[1], (P + pad_ext) * 4));
+    HIPCHK(ctx, alloc((void**)&w.q_vtx, 16));
+    HIPCHK(ctx, alloc((void**)&w.q_shadow, (P * (size_t)std::max(1u, n_lights) + pad_shadow) * 4));
     HIPCHK(ctx, alloc((void**)&w.counters, rt::WF_N_COUNTERS * sizeof(uint32_t)));
     HIPCHK(ctx, alloc((void**)&w.totals, 8 * sizeof(unsigned long long)));
     HIPCHK(ctx, alloc((void**)&w.accum, (size_t)std::max(1u, n_blocks) * 64 * 16));

@@ -56,6 +56,8 @@ struct WfBuffers {
 #define RT_WF_MAX_LIGHTS 32u /* visibility is one bit per light in a 32-bit word */
 #define RT_WF_ID_MASK 0x07FFFFFFu
 
+uint32_t wf_shading_blocks(); // grid size (256-thread blocks) of the generate / shade / finish kernels
+uint32_t wf_window(uint32_t n_lights); // queue slots a producing wave reserves per atomic (shadow queue: >= 64 * n_lights)
 uint32_t wf_persistent_waves(); // grid size (in 64-lane blocks) of the persistent traversal kernels on the current device
 hipError_t wf_generate(const DevScene& sc, const DevFrame& fr, const WfBuffers& wb, uint32_t first_sample, uint32_t n_samples, hipStream_t s);
 hipError_t wf_bounce(const DevScene& sc, const DevFrame& fr, const WfBuffers& wb, uint32_t iteration, bool counters, hipStream_t s);

@@ -12,15 +12,23 @@
 // kernels.hip); queues only change WHEN a path's next step runs, so images stay bit-identical.
 #include "wavefront.h"
 
+#include <algorithm>
+
 #include "device_common.h"
 
 using namespace rtdev;
 
+#ifndef RT_WF_MIN_WAVES
+#define RT_WF_MIN_WAVES 6 /* waves per SIMD the traversal kernels are register-allocated for */
+#endif
 #ifndef RT_WF_REFILL
 #define RT_WF_REFILL 16 /* idle lanes in a wave before it fetches new segments */
 #endif
 #ifndef RT_WF_CHUNK
 #define RT_WF_CHUNK 256 /* queue entries a wave claims per atomic */
+#endif
+#ifndef RT_WF_WINDOW
+#define RT_WF_WINDOW 512 /* queue slots a producing wave reserves per atomic */
 #endif
 #ifndef RT_WF_LEAF_THRESHOLD
 #define RT_WF_LEAF_THRESHOLD 24 /* lanes holding a postponed leaf before the triangle tests run */
@@ -34,40 +42,93 @@ namespace {
 
 __device__ __forceinline__ V3 f4v(float4 a) { return v3(a.x, a.y, a.z); }
 
+// Queue output through wave-private windows.  A single counter sustains ~90 M atomics/s (MI355X_MICROARCH.md,
+// "dequeue"); one atomic per wave-iteration (1.7 M per stage and bounce at 8 spp) made the shading stages
+// atomic-bound.  Here a wave reserves RT_WF_WINDOW (or more) slots per atomic and hands them out itself; what
+// it does not use is filled with WF_SENTINEL entries, which the consumers skip.  Real entries are tallied
+// separately (totals) because queue lengths now include the padding.
+struct OutWindow {
+    uint32_t next, end; // wave-uniform
+};
+#define WF_SENTINEL 0xFFFFFFFFu
+__device__ __forceinline__ void window_close(uint32_t* __restrict__ queue, OutWindow& w) {
+    for (uint32_t i = w.next + (threadIdx.x & 63u); i < w.end; i += WAVE) queue[i] = WF_SENTINEL;
+    w.next = w.end;
+}
+// returns the first slot for this lane; `mine` entries per lane, `incl` = inclusive prefix of `mine` over the wave
+__device__ __forceinline__ uint32_t window_reserve(uint32_t* __restrict__ queue, uint32_t* __restrict__ counter, OutWindow& w, uint32_t window,
+                                                  uint32_t mine, uint32_t incl, uint32_t total) {
+    if (w.next + total > w.end) {
+        window_close(queue, w);
+        uint32_t base = 0;
+        const uint32_t want = max(window, total);
+        if ((threadIdx.x & 63u) == 0) base = atomicAdd(counter, want);
+        base = __shfl(base, 0, WAVE);
+        w.next = base;
+        w.end = base + want;
+    }
+    const uint32_t at = w.next + incl - mine;
+    w.next += total;
+    return at;
+}
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+        const uint32_t u = __shfl_up(v, off, WAVE);
+        if ((int)lane >= off) v += u;
+    }
+    return v;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // generation: one lane per path slot (sample k of pixel (block b, lane l))
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WAVE) void k_wf_generate(DevFrame fr, rt::WfBuffers wb, uint32_t first_sample) {
-    const uint32_t lane = threadIdx.x;
-    const uint32_t k = blockIdx.x / wb.n_blocks, b = blockIdx.x - k * wb.n_blocks;
-    const PixelCoord px = block_pixel_at(fr, b, lane);
-    const uint32_t p = blockIdx.x * WAVE + lane;
-    if (px.valid) {
-        SimpleRng rng = rng_for(fr.frame_seed + px.x + px.y * fr.width, first_sample + k);
-        float jx = 0.5f, jy = 0.5f;
-        if (fr.spp > 1) {
-            jx = rng.next_f32();
-            jy = rng.next_f32();
+__global__ __launch_bounds__(256) void k_wf_generate(DevFrame fr, rt::WfBuffers wb, uint32_t first_sample, uint32_t n_slots_blocks) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_waves = gridDim.x * 4u, wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    OutWindow win = {0u, 0u};
+    uint32_t real = 0;
+    for (uint32_t sb = wave; sb < n_slots_blocks; sb += n_waves) { // sb = k * n_blocks + b
+        const uint32_t k = sb / wb.n_blocks, b = sb - k * wb.n_blocks;
+        const PixelCoord px = block_pixel_at(fr, b, lane);
+        const uint32_t p = sb * WAVE + lane;
+        if (px.valid) {
+            SimpleRng rng = rng_for(fr.frame_seed + px.x + px.y * fr.width, first_sample + k);
+            float jx = 0.5f, jy = 0.5f;
+            if (fr.spp > 1) {
+                jx = rng.next_f32();
+                jy = rng.next_f32();
+            }
+            V3 o, d;
+            camera_ray(fr.cam, (float)px.x + jx, (float)px.y + jy, true, o, d);
+            wb.ray_o[p] = make_float4(o.x, o.y, o.z, 0.0f);
+            wb.ray_d[p] = make_float4(d.x, d.y, d.z, 0.0f);
+            wb.thr[p] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(3u)); // channel 3 (none), depth 0
+            wb.rad[p] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(rng.seed));
+            wb.pxy[p] = px.x | (px.y << 16);
+        } else {
+            wb.pxy[p] = 0xFFFFFFFFu;
+            wb.sample_rad[p] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
-        V3 o, d;
-        camera_ray(fr.cam, (float)px.x + jx, (float)px.y + jy, true, o, d);
-        wb.ray_o[p] = make_float4(o.x, o.y, o.z, 0.0f);
-        wb.ray_d[p] = make_float4(d.x, d.y, d.z, 0.0f);
-        wb.thr[p] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(3u)); // channel 3 (none), depth 0
-        wb.rad[p] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(rng.seed));
-        wb.pxy[p] = px.x | (px.y << 16);
-    } else {
-        wb.pxy[p] = 0xFFFFFFFFu;
-        wb.sample_rad[p] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const uint32_t mine = px.valid ? 1u : 0u;
+        const uint32_t incl = wave_incl_scan(mine), total = __shfl(incl, WAVE - 1, WAVE);
+        if (total) {
+            const uint32_t at = window_reserve(wb.q_ext[0], &wb.counters[rt::WF_EXT_COUNT], win, RT_WF_WINDOW, mine, incl, total);
+            if (mine) wb.q_ext[0][at] = p;
+            real += mine;
+        }
     }
-    wave_append(wb.q_ext[0], &wb.counters[rt::WF_EXT_COUNT], px.valid, p);
+    window_close(wb.q_ext[0], win);
+    const unsigned long long r = wave_sum(real);
+    if (lane == 0 && r) atomicAdd(&wb.totals[0], r);
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // persistent traversal kernel (closest hit for extension segments, any hit for shadow segments)
 // ---------------------------------------------------------------------------------------------------------
 template <bool COUNT, bool ANY>
-__global__ __launch_bounds__(WAVE) void k_wf_trace(DevScene sc, rt::WfBuffers wb, const uint32_t* __restrict__ queue, uint32_t count_slot,
+__global__ __launch_bounds__(WAVE, RT_WF_MIN_WAVES) void k_wf_trace(DevScene sc, rt::WfBuffers wb, const uint32_t* __restrict__ queue, uint32_t count_slot,
                                                    uint32_t cursor_slot) {
     extern __shared__ uint32_t s_stack[];
     const uint32_t lane = threadIdx.x;
@@ -111,8 +172,9 @@ __global__ __launch_bounds__(WAVE) void k_wf_trace(DevScene sc, rt::WfBuffers wb
             if (!exhausted) {
                 const uint32_t idx = chunk_next + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
                 chunk_next += (uint32_t)__popcll(idle);
-                if (!active && idx < chunk_end) {
-                    const uint32_t e = queue[idx];
+                uint32_t e = WF_SENTINEL;
+                if (!active && idx < chunk_end) e = queue[idx];
+                if (e != WF_SENTINEL) { // padding entries of the producers' windows carry no work
                     if (ANY) {
                         id = e & RT_WF_ID_MASK;
                         li = e >> 27;
@@ -216,16 +278,17 @@ __global__ __launch_bounds__(256) void k_wf_shade(DevScene sc, DevFrame fr, rt::
     const uint32_t count = wb.counters[rt::WF_EXT_COUNT];
     const bool shadows = (fr.flags & 2u) == 0;
     const uint32_t stride = gridDim.x * blockDim.x;
+    OutWindow win = {0u, 0u};
+    uint32_t n_shadow = 0;
     // every wave runs the same number of iterations so the wave-aggregated appends see whole waves
     for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += stride) {
         const uint32_t i = base + threadIdx.x;
-        const bool have = i < count;
-        uint32_t id = 0;
+        uint32_t id = i < count ? queue[i] : WF_SENTINEL;
+        const bool have = id != WF_SENTINEL;
         bool vertex = false;
         V3 point = v3(0, 0, 0), normal = point;
         uint32_t material_id = 0;
         if (have) {
-            id = queue[i];
             const uint4 h = wb.hit[id];
             const float4 th = wb.thr[id], ra = wb.rad[id];
             const V3 throughput = f4v(th);
@@ -265,19 +328,10 @@ __global__ __launch_bounds__(256) void k_wf_shade(DevScene sc, DevFrame fr, rt::
                 }
             }
             const uint32_t mine = (uint32_t)__popc(mask);
-            uint32_t incl = mine;
-            const uint32_t lane = threadIdx.x & 63u;
-#pragma unroll
-            for (int off = 1; off < WAVE; off <<= 1) {
-                const uint32_t v = __shfl_up(incl, off, WAVE);
-                if ((int)lane >= off) incl += v;
-            }
-            const uint32_t total = __shfl(incl, WAVE - 1, WAVE);
+            const uint32_t incl = wave_incl_scan(mine), total = __shfl(incl, WAVE - 1, WAVE);
             if (total) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&wb.counters[rt::WF_SHADOW_COUNT], total);
-                base = __shfl(base, 0, WAVE);
-                uint32_t at = base + incl - mine;
+                uint32_t at = window_reserve(wb.q_shadow, &wb.counters[rt::WF_SHADOW_COUNT], win, max((uint32_t)RT_WF_WINDOW, sc.n_lights * WAVE), mine, incl, total);
+                n_shadow += mine;
                 while (mask) {
                     const uint32_t li = (uint32_t)__ffs((int)mask) - 1u;
                     mask &= mask - 1u;
@@ -286,6 +340,9 @@ __global__ __launch_bounds__(256) void k_wf_shade(DevScene sc, DevFrame fr, rt::
             }
         }
     }
+    window_close(wb.q_shadow, win);
+    const unsigned long long ns = wave_sum(n_shadow);
+    if ((threadIdx.x & 63u) == 0 && ns) atomicAdd(&wb.totals[2], ns);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -296,15 +353,16 @@ __global__ __launch_bounds__(256) void k_wf_finish(DevScene sc, DevFrame fr, rt:
     const uint32_t count = wb.counters[rt::WF_EXT_COUNT];
     const bool shadows = (fr.flags & 2u) == 0;
     const uint32_t stride = gridDim.x * blockDim.x;
+    OutWindow win = {0u, 0u};
+    uint32_t n_cont = 0;
     for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += stride) {
         const uint32_t i = base + threadIdx.x;
         bool cont = false;
         uint32_t id = 0;
         float4 vp = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
-        if (i < count) {
-            id = queue[i];
-            vp = wb.vtx_p[id];
-        }
+        if (i < count) id = queue[i];
+        else id = WF_SENTINEL;
+        if (id != WF_SENTINEL) vp = wb.vtx_p[id];
         if (__float_as_uint(vp.w) != 0xFFFFFFFFu) { // paths that ended in k_wf_shade carry the "no vertex" marker
 
             const V3 point = f4v(vp), normal = f4v(wb.vtx_n[id]);
@@ -399,15 +457,23 @@ __global__ __launch_bounds__(256) void k_wf_finish(DevScene sc, DevFrame fr, rt:
                 }
             }
         }
-        wave_append(next_queue, &wb.counters[rt::WF_EXT_NEXT], cont, id);
+        const uint32_t mine = cont ? 1u : 0u;
+        const uint32_t incl = wave_incl_scan(mine), total = __shfl(incl, WAVE - 1, WAVE);
+        if (total) {
+            const uint32_t at = window_reserve(next_queue, &wb.counters[rt::WF_EXT_NEXT], win, RT_WF_WINDOW, mine, incl, total);
+            if (cont) next_queue[at] = id;
+            n_cont += mine;
+        }
     }
+    window_close(next_queue, win);
+    const unsigned long long nc = wave_sum(n_cont);
+    if ((threadIdx.x & 63u) == 0 && nc) atomicAdd(&wb.totals[1], nc);
 }
 
 __global__ void k_wf_advance(rt::WfBuffers wb, uint32_t iteration) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     uint32_t* c = wb.counters;
-    wb.totals[iteration == 0 ? 0 : 1] += c[rt::WF_EXT_COUNT];
-    wb.totals[2] += c[rt::WF_SHADOW_COUNT];
+    (void)iteration; // segment totals are tallied by the producing kernels (queue lengths include window padding)
     c[rt::WF_EXT_COUNT] = c[rt::WF_EXT_NEXT];
     c[rt::WF_EXT_NEXT] = 0;
     c[rt::WF_VTX_COUNT] = 0;
@@ -454,20 +520,22 @@ int cu_count() {
 
 namespace rt {
 
+uint32_t wf_shading_blocks() { return (uint32_t)(cu_count() * 8); }
+uint32_t wf_window(uint32_t n_lights) { return std::max<uint32_t>(RT_WF_WINDOW, n_lights * WAVE); }
 uint32_t wf_persistent_waves() { return (uint32_t)(cu_count() * RT_WF_WAVES_PER_CU); }
 
 hipError_t wf_generate(const DevScene&, const DevFrame& fr, const WfBuffers& wb, uint32_t first_sample, uint32_t n_samples, hipStream_t s) {
     hipError_t e = hipMemsetAsync(wb.counters, 0, WF_N_COUNTERS * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
     if (wb.n_blocks == 0 || n_samples == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_wf_generate, dim3(n_samples * wb.n_blocks), dim3(WAVE), 0, s, fr, wb, first_sample);
+    hipLaunchKernelGGL(k_wf_generate, dim3(wf_shading_blocks()), dim3(256), 0, s, fr, wb, first_sample, n_samples * wb.n_blocks);
     return hipGetLastError();
 }
 
 hipError_t wf_bounce(const DevScene& sc, const DevFrame& fr, const WfBuffers& wb, uint32_t iteration, bool counters, hipStream_t s) {
     const size_t lds = (size_t)RT_WF_LDS_STACK * WAVE * sizeof(uint32_t);
     const dim3 pgrid(wf_persistent_waves()), pblock(WAVE);
-    const dim3 sgrid((unsigned)(cu_count() * 8)), sblock(256);
+    const dim3 sgrid(wf_shading_blocks()), sblock(256);
     uint32_t* cur_q = wb.q_ext[iteration & 1u];
     uint32_t* next_q = wb.q_ext[(iteration + 1u) & 1u];
     if (counters)
