@@ -27,6 +27,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 S_OUT_BYTES = 16 + 12 + 8  # per pixel: RGBA32F + three unorm8 texels + (prim id, t) hit record
+S_STATE_BYTES = 2 * 76  # per segment through the wavefront queues: one WavefrontRay-sized record written and read
 
 
 def parse_args():
@@ -40,6 +41,8 @@ def parse_args():
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--bounces", type=int, default=4)
     ap.add_argument("--mode", default="auto", choices=["auto", "reference", "extended"])
+    ap.add_argument("--kernel", default="wavefront", choices=["wavefront", "state_machine", "nested"],
+                    help="extended-mode implementation (all three produce identical images)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default=None, help="resolution of the bounded CPU-baseline sample (default 960x540 "
                     "for the reference mode, 160x90 at <= 4 spp for the extended mode)")
@@ -188,7 +191,8 @@ def main():
 
     def step(counters=False):
         return ctx.render(args.width, args.height, scene.camera, mode=mode, spp=spp, max_bounces=bounces,
-                          tile_rank=rank, tile_world=n_gpus, counters=counters)
+                          tile_rank=rank, tile_world=n_gpus, counters=counters,
+                          kernel_sm=args.kernel == "state_machine", kernel_v1=args.kernel == "nested")
 
     for _ in range(args.warmup):
         step()
@@ -206,6 +210,8 @@ def main():
     # algorithmic bytes of one launch on this rank: exact node / triangle fetch counts from the counting variant
     stc = step(counters=True)
     alg_bytes = stc["node_visits"] * stc["node_bytes"] + stc["tri_tests"] * stc["tri_bytes"] + stc["pixels"] * S_OUT_BYTES
+    if mode_name == "extended" and args.kernel == "wavefront":
+        alg_bytes += stc["rays"] * S_STATE_BYTES
     avg_kernel_ms = float(np.mean(kernel_ms))
     achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
 
@@ -220,6 +226,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "scene": scene.name, "triangles": scene.n_triangles,
                        "resolution": [args.width, args.height], "spp": spp, "mode": mode_name,
+                       "implementation": args.kernel if mode_name == "extended" else "k_render_reference",
                        "partition": f"tiles {tile}x{tile} interleaved over {n_gpus} rank(s), scene replicated, no collective",
                        "bounces": bounces if mode_name == "extended" else 0,
                        "rays_per_step": total_rays / args.steps,
@@ -227,10 +234,12 @@ def main():
                        "kernel_mrays_per_s_rank0": stc["rays"] / avg_kernel_ms / 1e3},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(f"{scene.name}_{args.width}x{args.height}_{mode_name}"),
-                         "kernel": "k_render_reference" if mode_name == "reference" else "k_render_extended",
+                         "kernel": "k_render_reference" if mode_name == "reference" else
+                                   "wavefront pipeline (k_wf_trace<shadow> + k_wf_trace<closest> + k_wf_shade + k_wf_finish + k_wf_generate)",
                          "kernel_avg_ms": avg_kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
                          "nodes_per_ray": stc["node_visits"] / max(stc["rays"], 1), "tris_per_ray": stc["tri_tests"] / max(stc["rays"], 1),
-                         "note": "algorithmic bytes = node fetches x 48 B + triangle fetches x 48 B + pixels x 36 B (rank 0's share); "
+                         "note": "algorithmic bytes = node fetches x 48 B + triangle fetches x 48 B + pixels x 36 B + (wavefront) segments x 152 B of "
+                                 "queue state (rank 0's share); kernel_avg_ms is the HIP-event time of all stage kernels of one frame; "
                                  "the 23 MB scene is cache resident, so this exceeds what HBM itself moves (see traffic)"},
         }
         if n_gpus == 1 and not args.no_cpu_baseline:

@@ -1,48 +1,58 @@
 """Turn a gpurun_out/prof_<tag>/ directory (scripts/profile_r01.sh) into the committed summaries under profiles/.
 
-  python scripts/summarize_profile.py gpurun_out/prof_r01b profiles/r01_extended_sponza1080p_64spp [--workload KEY]
+  python scripts/summarize_profile.py gpurun_out/prof_X profiles/NAME --frames N [--workload KEY] [--match k_wf_]
 
-Writes <out>_kernel_stats.csv (verbatim rocprofv3 --kernel-trace --stats summary), <out>_pmc.json (per-launch
-counter means for the dominant kernel) and merges the HBM traffic into profiles/traffic.json under KEY.
-HBM bytes follow MI355X_MICROARCH.md §HBM: FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reads half the
-bytes of a wide coalesced streaming read, so the read side is reported as a [x1, x2] bracket with the x2 value
-used for `traffic` (conservative: more traffic, lower efficiency)."""
+Writes <out>_kernel_stats.csv (verbatim rocprofv3 --kernel-trace --stats summary), <out>_pmc.json (per-FRAME counter
+sums over every dispatch of the measured kernels: one frame of the wavefront pipeline is ~26 launches per batch) and
+merges the HBM traffic per frame into profiles/traffic.json under KEY.
+HBM bytes follow MI355X_MICROARCH.md, HBM section: FETCH_SIZE / WRITE_SIZE are in KiB, collected in separate --pmc
+passes; on gfx950 FETCH_SIZE reads half the bytes of a wide coalesced streaming read, so the read side is reported as
+an [x1, x2] bracket and `traffic` uses the x2 value (conservative: more traffic)."""
 import csv, glob, json, os, shutil, sys, collections
 
 src, out = sys.argv[1], sys.argv[2]
-key = sys.argv[sys.argv.index("--workload") + 1] if "--workload" in sys.argv else None
+arg = lambda k, d=None: sys.argv[sys.argv.index(k) + 1] if k in sys.argv else d
+key, frames, match = arg("--workload"), int(arg("--frames", "1")), arg("--match", "k_render")
 os.makedirs(os.path.dirname(out), exist_ok=True)
 stats = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[0]
 shutil.copy(stats, out + "_kernel_stats.csv")
-rows = list(csv.DictReader(open(stats)))
-dom = max((r for r in rows if "k_render" in r["Name"] and "<true>" not in r["Name"]), key=lambda r: float(r["TotalDurationNs"]))
-summary = {"kernel": dom["Name"], "calls": int(dom["Calls"]), "avg_ns": float(dom["AverageNs"]), "min_ns": float(dom["MinNs"]), "max_ns": float(dom["MaxNs"])}
-kname = dom["Name"]
+import re
+rows = [r for r in csv.DictReader(open(stats)) if match in r["Name"] and "<true" not in r["Name"]]
+
+
+def kname(full):
+    n = re.search(r"(k_[a-z_0-9]+)", full).group(1)
+    return n + ("<shadow>" if "<false, true>" in full else "<closest>" if "<false, false>" in full else "")
+
+
+# bench.py renders warmup + steps frames plus ONE more with the counting kernel variants (<true, ...>, excluded
+# here); kernels that are not templated on COUNT also run in that extra frame
+nframes = lambda full: frames if "<" in full else frames + 1
+summary = {"frames": frames, "kernels": {kname(r["Name"]): {"calls": int(r["Calls"]), "total_ms_per_frame": float(r["TotalDurationNs"]) / 1e6 / nframes(r["Name"]),
+                                                             "avg_us": float(r["AverageNs"]) / 1e3} for r in rows}}
+summary["kernel_ms_per_frame"] = sum(v["total_ms_per_frame"] for v in summary["kernels"].values())
 pmc = {}
 for d in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq"):
     fs = glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv"))
     if not fs:
         continue
-    agg = collections.defaultdict(list)
+    agg = collections.defaultdict(float)
     for r in csv.DictReader(open(fs[0])):
-        if r["Kernel_Name"] == kname:
-            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-            pmc.setdefault("_meta", {"VGPR_Count": r["VGPR_Count"], "SGPR_Count": r["SGPR_Count"], "LDS_Block_Size": r["LDS_Block_Size"],
-                                     "Scratch_Size": r["Scratch_Size"], "Grid_Size": r["Grid_Size"], "Workgroup_Size": r["Workgroup_Size"]})
+        if match in r["Kernel_Name"] and "<true" not in r["Kernel_Name"]:
+            agg[r["Counter_Name"]] += float(r["Counter_Value"]) / nframes(r["Kernel_Name"])
     for k, v in agg.items():
-        pmc[k] = {"mean": sum(v) / len(v), "min": min(v), "max": max(v), "n": len(v)}
-summary["pmc"] = pmc
+        pmc[k] = v
+summary["pmc_per_frame"] = pmc
 if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
-    rd, wr = pmc["FETCH_SIZE"]["mean"] * 1024, pmc["WRITE_SIZE"]["mean"] * 1024
-    summary["hbm_bytes_per_launch"] = {"read_x1": rd, "read_x2_gfx950_corrected": 2 * rd, "write": wr, "traffic": 2 * rd + wr}
+    rd, wr = pmc["FETCH_SIZE"] * 1024, pmc["WRITE_SIZE"] * 1024
+    summary["hbm_bytes_per_frame"] = {"read_x1": rd, "read_x2_gfx950_corrected": 2 * rd, "write": wr, "traffic": 2 * rd + wr}
     if key:
         tp = os.path.join(os.path.dirname(out), "traffic.json")
         t = json.load(open(tp)) if os.path.exists(tp) else {}
         t[key] = 2 * rd + wr
         json.dump(t, open(tp, "w"), indent=1, sort_keys=True)
 if "TCC_HIT_sum" in pmc:
-    h, m = pmc["TCC_HIT_sum"]["mean"], pmc["TCC_MISS_sum"]["mean"]
-    summary["l2_hit_rate"] = h / (h + m)
+    summary["l2_hit_rate"] = pmc["TCC_HIT_sum"] / (pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"])
 for f in glob.glob(os.path.join(src, "bench_*.json")):
     try:
         line = [l for l in open(f).read().splitlines() if l.startswith("{")][-1]
@@ -50,4 +60,4 @@ for f in glob.glob(os.path.join(src, "bench_*.json")):
     except Exception:
         pass
 json.dump(summary, open(out + "_pmc.json", "w"), indent=1)
-print(json.dumps({k: v for k, v in summary.items() if k != "bench_lines"}, indent=1)[:3000])
+print(json.dumps({k: v for k, v in summary.items() if k != "bench_lines"}, indent=1)[:3500])
