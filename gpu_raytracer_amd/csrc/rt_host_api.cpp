@@ -2,8 +2,18 @@
 #include "../../include/rt_host.h"
 
 #include "host/raytracer_host.hpp"
+#include "host/gltf_loader.hpp"
+#include "host/image_io.hpp"
 
 using namespace raytracer;
+
+namespace {
+thread_local double g_timing[7] = {0, 0, 0, 0, 0, 0, 0};
+}
+
+struct rt_host_scene {
+    LoadedScene scene;
+};
 
 extern "C" {
 
@@ -113,14 +123,97 @@ int rt_host_render_progressive(rt_ctx* ctx, const rt_sphere* spheres, uint32_t n
     progressive.resize(width, height);
     uint32_t calls = 0;
     bool done = false;
+    std::vector<double> call_ms;
+    const auto t_start = std::chrono::steady_clock::now();
     while (!done) {
+        const auto t0 = std::chrono::steady_clock::now();
         int rc = ComputeRenderer::run_compute(ctx, buffers, scene, progressive, &done);
         if (rc != RT_OK) return rc;
+        call_ms.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         if (++calls > 1000000u) return RT_ERR_INTERNAL;
+    }
+    { // print_completion_summary's numbers (src/compute.rs:320-363), returned instead of printed
+        const double total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+        std::sort(call_ms.begin(), call_ms.end());
+        auto pct = [&](double p) { return call_ms.empty() ? 0.0 : call_ms[std::min(call_ms.size() - 1, (size_t)(p * (double)call_ms.size()))]; };
+        const double tiles = (double)progressive.tiles_x * progressive.tiles_y;
+        g_timing[0] = total;
+        g_timing[1] = (double)calls;
+        g_timing[2] = tiles;
+        g_timing[3] = total > 0 ? tiles / (total / 1000.0) : 0.0;
+        g_timing[4] = pct(0.50);
+        g_timing[5] = pct(0.95);
+        g_timing[6] = pct(0.99);
     }
     if (n_dispatches) *n_dispatches = progressive.tiles_x * progressive.tiles_y * 3;
     if (n_calls) *n_calls = calls;
     return RT_OK;
+}
+
+static int gltf_finish(GltfLoader& loader, GltfError e, int scene_index, rt_host_scene** out, char* err, size_t err_len) {
+    std::unique_ptr<rt_host_scene> h(new rt_host_scene());
+    if (!e) e = loader.extract_scene(scene_index, h->scene);
+    if (e) {
+        if (err && err_len) std::snprintf(err, err_len, "%s", e.message.c_str());
+        return e.kind == GltfError::IoError ? RT_HOST_ERR_IO : e.kind == GltfError::ValidationError ? RT_HOST_ERR_VALIDATION : RT_HOST_ERR_GLTF;
+    }
+    *out = h.release();
+    return RT_OK;
+}
+
+int rt_host_gltf_load(const char* path, int scene_index, rt_host_scene** out, char* err, size_t err_len) {
+    if (!path || !out) return RT_ERR_BAD_ARG;
+    *out = nullptr;
+    GltfLoader loader;
+    GltfError e = GltfLoader::load_from_path(path, loader);
+    return gltf_finish(loader, e, scene_index, out, err, err_len);
+}
+
+int rt_host_gltf_load_glb(const uint8_t* data, size_t len, int scene_index, rt_host_scene** out, char* err, size_t err_len) {
+    if (!data || !out) return RT_ERR_BAD_ARG;
+    *out = nullptr;
+    GltfLoader loader;
+    GltfError e = GltfLoader::load_from_glb(data, len, loader);
+    return gltf_finish(loader, e, scene_index, out, err, err_len);
+}
+
+void rt_host_scene_counts(const rt_host_scene* s, uint32_t counts[6]) {
+    const LoadedScene& l = s->scene;
+    counts[0] = (uint32_t)l.spheres.size();
+    counts[1] = (uint32_t)l.lights.size();
+    counts[2] = (uint32_t)l.vertices.size();
+    counts[3] = (uint32_t)l.triangles.size();
+    counts[4] = (uint32_t)l.materials.size();
+    counts[5] = (uint32_t)l.cameras.size();
+}
+
+int rt_host_scene_copy(const rt_host_scene* s, rt_sphere* spheres, rt_light* lights, rt_vertex* vertices, rt_triangle* triangles,
+                       rt_material* materials, rt_camera* cameras) {
+    if (!s) return RT_ERR_BAD_ARG;
+    const LoadedScene& l = s->scene;
+    if (spheres) std::copy(l.spheres.begin(), l.spheres.end(), spheres);
+    if (lights) std::copy(l.lights.begin(), l.lights.end(), lights);
+    if (vertices) std::copy(l.vertices.begin(), l.vertices.end(), vertices);
+    if (triangles) std::copy(l.triangles.begin(), l.triangles.end(), triangles);
+    if (materials) std::copy(l.materials.begin(), l.materials.end(), materials);
+    if (cameras) std::copy(l.cameras.begin(), l.cameras.end(), cameras);
+    return RT_OK;
+}
+
+void rt_host_scene_free(rt_host_scene* s) { delete s; }
+
+int rt_host_write_ppm(const char* path, const uint8_t* rgba8, uint32_t width, uint32_t height) {
+    if (!path || !rgba8 || !width || !height) return RT_ERR_BAD_ARG;
+    return write_ppm(path, rgba8, width, height) ? RT_OK : RT_HOST_ERR_IO;
+}
+
+int rt_host_write_png(const char* path, const uint8_t* rgba8, uint32_t width, uint32_t height) {
+    if (!path || !rgba8 || !width || !height) return RT_ERR_BAD_ARG;
+    return write_png(path, rgba8, width, height) ? RT_OK : RT_HOST_ERR_IO;
+}
+
+void rt_host_progressive_timing(double out[7]) {
+    for (int i = 0; i < 7; i++) out[i] = g_timing[i];
 }
 
 } // extern "C"

@@ -119,3 +119,82 @@ def render_progressive(ctx, scene, width, height, camera=None):
     ctx._check(rc)
     ctx.width, ctx.height = width, height
     return nd.value, nc.value
+
+
+# ---- row N1: glTF loading -----------------------------------------------------------------------------
+HOST_SYMBOLS += ["rt_host_gltf_load", "rt_host_gltf_load_glb", "rt_host_scene_counts", "rt_host_scene_copy", "rt_host_scene_free",
+                 "rt_host_write_ppm", "rt_host_write_png", "rt_host_progressive_timing"]
+GLTF_ERRORS = {-11: "IoError", -12: "GltfError", -13: "ValidationError"}
+
+
+class GltfError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"{GLTF_ERRORS.get(code, code)}: {msg}")
+        self.code = code
+
+
+def _scene_from_handle(lib, h, name):
+    from . import hostpack as H
+    from .scenes import Scene
+    counts = (C.c_uint32 * 6)()
+    lib.rt_host_scene_counts(h, counts)
+    sp, li, ve = np.zeros(counts[0], T.SPHERE), np.zeros(counts[1], T.LIGHT), np.zeros(counts[2], T.VERTEX)
+    tr, ma, ca = np.zeros(counts[3], T.TRIANGLE), np.zeros(counts[4], T.MATERIAL), np.zeros(counts[5], T.CAMERA)
+    lib.rt_host_scene_copy(h, _p(sp), _p(li), _p(ve), _p(tr), _p(ma), _p(ca))
+    lib.rt_host_scene_free(h)
+    # SceneState::load_from_gltf (src/scene.rs:43-69): first camera of the file, else Camera::new
+    cam = ca[0].copy() if len(ca) else H.camera()
+    return Scene(name, sp, li, ve, tr, ma, cam, {"cameras": ca})
+
+
+def load_gltf(path, scene_index=-1):
+    """GltfLoader::load_from_path + extract_scene -> Scene (camera = first camera or Camera::new)."""
+    lib = _lib()
+    lib.rt_host_gltf_load.restype = C.c_int
+    lib.rt_host_scene_free.restype = None
+    lib.rt_host_scene_free.argtypes = [C.c_void_p]
+    lib.rt_host_scene_counts.restype = None
+    lib.rt_host_scene_counts.argtypes = [C.c_void_p, C.c_void_p]
+    lib.rt_host_scene_copy.argtypes = [C.c_void_p] * 7
+    h = C.c_void_p(0)
+    err = C.create_string_buffer(512)
+    rc = lib.rt_host_gltf_load(str(path).encode(), C.c_int(scene_index), C.byref(h), err, C.c_size_t(512))
+    if rc != 0:
+        raise GltfError(rc, err.value.decode())
+    return _scene_from_handle(lib, h, str(path))
+
+
+def load_glb(data, scene_index=-1):
+    lib = _lib()
+    lib.rt_host_gltf_load_glb.restype = C.c_int
+    lib.rt_host_scene_free.restype = None
+    lib.rt_host_scene_free.argtypes = [C.c_void_p]
+    lib.rt_host_scene_counts.restype = None
+    lib.rt_host_scene_counts.argtypes = [C.c_void_p, C.c_void_p]
+    lib.rt_host_scene_copy.argtypes = [C.c_void_p] * 7
+    h = C.c_void_p(0)
+    err = C.create_string_buffer(512)
+    buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+    rc = lib.rt_host_gltf_load_glb(buf, C.c_size_t(len(data)), C.c_int(scene_index), C.byref(h), err, C.c_size_t(512))
+    if rc != 0:
+        raise GltfError(rc, err.value.decode())
+    return _scene_from_handle(lib, h, "glb")
+
+
+# ---- rows N3 / N4 ------------------------------------------------------------------------------------
+def write_image(path, rgba8):
+    img = np.ascontiguousarray(rgba8, dtype=np.uint8)
+    h, w = img.shape[:2]
+    fn = _lib().rt_host_write_png if str(path).lower().endswith(".png") else _lib().rt_host_write_ppm
+    fn.restype = C.c_int
+    rc = fn(str(path).encode(), _p(img), C.c_uint32(w), C.c_uint32(h))
+    if rc != 0:
+        raise OSError(f"cannot write {path} ({rc})")
+
+
+def progressive_timing():
+    out = (C.c_double * 7)()
+    fn = _lib().rt_host_progressive_timing
+    fn.restype = None
+    fn(out)
+    return dict(zip(("total_ms", "calls", "tiles", "tiles_per_s", "p50_ms", "p95_ms", "p99_ms"), [float(v) for v in out]))

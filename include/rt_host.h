@@ -54,6 +54,31 @@ int rt_host_render_progressive(rt_ctx* ctx, const rt_sphere* spheres, uint32_t n
                                const rt_material* materials, uint32_t n_materials, const rt_camera* camera, uint32_t width,
                                uint32_t height, uint32_t* n_dispatches, uint32_t* n_calls);
 
+/* ---- row N1: glTF 2.0 / GLB loading with the behaviour of src/gltf_loader.rs (extract_scene :77-125) ---- */
+typedef struct rt_host_scene rt_host_scene;
+#define RT_HOST_ERR_IO (-11)         /* GltfError::IoError         */
+#define RT_HOST_ERR_GLTF (-12)       /* GltfError::GltfError       */
+#define RT_HOST_ERR_VALIDATION (-13) /* GltfError::ValidationError */
+/* GltfLoader::load_from_path + extract_scene(scene_index < 0 ? None : Some(i)).  err receives the message. */
+int rt_host_gltf_load(const char* path, int scene_index, rt_host_scene** out, char* err, size_t err_len);
+/* GltfLoader::load_from_glb + extract_scene */
+int rt_host_gltf_load_glb(const uint8_t* data, size_t len, int scene_index, rt_host_scene** out, char* err, size_t err_len);
+/* counts[6] = spheres, lights, vertices, triangles, materials, cameras of the LoadedScene */
+void rt_host_scene_counts(const rt_host_scene* s, uint32_t counts[6]);
+/* copy the LoadedScene's Vecs into caller arrays (each may be NULL) */
+int rt_host_scene_copy(const rt_host_scene* s, rt_sphere* spheres, rt_light* lights, rt_vertex* vertices, rt_triangle* triangles,
+                       rt_material* materials, rt_camera* cameras);
+void rt_host_scene_free(rt_host_scene* s);
+
+/* ---- row N3: image output (the reference has none) ---- */
+int rt_host_write_ppm(const char* path, const uint8_t* rgba8, uint32_t width, uint32_t height);
+int rt_host_write_png(const char* path, const uint8_t* rgba8, uint32_t width, uint32_t height);
+
+/* ---- row N4: the reference's progressive completion summary (src/compute.rs:320-363) for the last
+ * rt_host_render_progressive on this thread: out[0] total ms, [1] calls, [2] tiles, [3] tiles/s,
+ * [4] p50, [5] p95, [6] p99 of the per-call time in ms ---- */
+void rt_host_progressive_timing(double out[7]);
+
 #ifdef __cplusplus
 }
 #endif

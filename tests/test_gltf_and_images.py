@@ -1,0 +1,154 @@
+"""Rows N1 / N3 / N4 of SURVEY.md §8f: the C++ glTF loader with the behaviour of src/gltf_loader.rs, the image
+writers, and the progressive completion summary.  Fixtures: tests/golden/*.gltf|glb (authored for this repository
+by tests/golden/make_gltf_fixtures.py; the reference's tests hold no glTF file)."""
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from gpu_raytracer_amd import host, hostpack as H, scenes, types as T
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _tri_pos(sc):
+    v = sc.vertices["position"]
+    return np.stack([v[sc.triangles[k]] for k in ("v0_index", "v1_index", "v2_index")], 1)
+
+
+@pytest.mark.parametrize("loader", ["gltf", "glb"])
+def test_cornell12_fixture_equals_the_harness_scene(loader):
+    s = host.load_gltf(os.path.join(GOLD, "cornell12.gltf")) if loader == "gltf" else host.load_glb(open(os.path.join(GOLD, "cornell12.glb"), "rb").read())
+    r = scenes.cornell12()
+    assert s.n_triangles == 12 and len(s.spheres) == 0
+    # per-primitive vertex deduplication (src/gltf_loader.rs:307-330): 6 quads x 4 corners, shared corners are NOT merged across primitives
+    assert len(s.vertices) == 24
+    assert s.materials.tobytes() == r.materials.tobytes()
+    assert s.lights.tobytes() == r.lights.tobytes()          # point light at (0,0.9,0), range inf -> f16 inf
+    assert s.camera.tobytes() == r.camera.tobytes()          # yfov pi/4 rad -> 45 degrees, camera looks down -Z
+    np.testing.assert_array_equal(_tri_pos(s), _tri_pos(r))
+    np.testing.assert_array_equal(s.triangles["material_id"], r.triangles["material_id"])
+
+
+def test_cornell12_gltf_renders_like_the_harness_scene_on_the_oracle(oracle_mod):
+    s = host.load_gltf(os.path.join(GOLD, "cornell12.gltf"))
+    a = oracle_mod.render_frame(oracle_mod.PackedScene(s), 96, 96)
+    b = oracle_mod.render_frame(oracle_mod.PackedScene(scenes.cornell12()), 96, 96)
+    np.testing.assert_array_equal(a["rgb"].view(np.uint32), b["rgb"].view(np.uint32))
+    np.testing.assert_array_equal(a["prim"], b["prim"])
+
+
+def test_modes_fixture_topologies_indices_transforms_and_materials():
+    s = host.load_gltf(os.path.join(GOLD, "modes.gltf"))
+    # strip 4 + fan 3 + three indexed quads (u8, u16, u32 with a dangling 7th index) 6 + non-indexed soup 1; LINES skipped
+    assert s.n_triangles == 14
+    tp = _tri_pos(s)
+    # node chain: root(scale 1) -> node0 (T(1,2,3) * R(90deg about Y) * S(2,1,0.5)); local (x,y,z) -> (1 + 0.5 z, 2 + y, 3 - 2 x)
+    def xf(p):
+        p = np.asarray(p, np.float64)
+        return np.stack([1 + 0.5 * p[..., 2], 2 + p[..., 1], 3 - 2 * p[..., 0]], -1)
+    strip = np.array([[0, 0, 0], [0, 1, 0], [1, 0, 0], [1, 1, 0], [2, 0, 0], [2, 1, 0]], np.float64)
+    want_strip = [xf(strip[[0, 1, 2]]), xf(strip[[1, 3, 2]]), xf(strip[[2, 3, 4]]), xf(strip[[3, 5, 4]])]  # odd triangles swap v1/v2
+    np.testing.assert_allclose(tp[:4], want_strip, atol=1e-5)
+    fan = np.array([[0, 0, 1], [1, 0, 1], [1, 1, 1], [0, 1.5, 1], [-1, 1, 1]], np.float64)
+    np.testing.assert_allclose(tp[4:7], [xf(fan[[0, 1, 2]]), xf(fan[[0, 2, 3]]), xf(fan[[0, 3, 4]])], atol=1e-5)
+    quad = np.array([[0, 0, 2], [1, 0, 2], [1, 1, 2], [0, 1, 2]], np.float64)
+    for k in (7, 9, 11):
+        np.testing.assert_allclose(tp[k:k + 2], [xf(quad[[0, 1, 2]]), xf(quad[[0, 2, 3]])], atol=1e-5)
+    np.testing.assert_allclose(tp[13], xf(np.array([[0, 0, 3], [1, 0, 3], [0, 1, 3]])), atol=1e-5)
+    # material ids: 0,1,2,3, none -> 0, out-of-range 99 -> 0 (material_map lookup fails, unwrap_or(0), :296-298)
+    assert s.triangles["material_id"].tolist() == [0] * 4 + [1] * 3 + [2] * 2 + [3] * 2 + [0] * 2 + [0]
+    # vertex dedup is per primitive: the three quad primitives each add their own 4 vertices
+    assert len(s.vertices) == 6 + 5 + 4 + 4 + 4 + 3
+    m0, m1, m2, m3 = s.materials
+    assert m0.tobytes()[:12] == np.array([0.2, 0.4, 0.6], np.float32).tobytes()
+    want0 = H.material_new((0.2, 0.4, 0.6), 0.75, 0.25, (0.1, 0.2, 0.3), 1.33, 0.6)
+    assert int(m0["metallic_roughness_f16"]) == int(want0["metallic_roughness_f16"]) and int(m0["ior_transmission_f16"]) == int(want0["ior_transmission_f16"])
+    np.testing.assert_array_equal(m0["emission"], np.array([0.1, 0.2, 0.3], np.float32))
+    assert m0["specular_factor"] == np.float32(0.5) and m0["thickness_factor"] == np.float32(0.2) and m0["attenuation_distance"] == np.float32(4.0)
+    np.testing.assert_array_equal(m0["attenuation_color"], np.array([0.5, 0.6, 0.7], np.float32))
+    assert m1["material_type"] == 1 and m1["glossiness_factor"] == np.float32(0.7)  # Material::specular_glossiness
+    np.testing.assert_array_equal(m1["specular_color"], np.array([0.4, 0.5, 0.6], np.float32))
+    assert int(m1["metallic_roughness_f16"]) >> 16 == H.f16_bits(np.float32(1.0) - np.float32(0.7))
+    assert m2.tobytes() == H.material_new((1, 1, 1), 1.0, 1.0, (0, 0, 0), 1.5, 0.0).tobytes()  # glTF defaults
+    assert m3["texture_indices"].tolist() == [2, 0, 1, 3] + [0xFFFFFFFF] * 4
+    # lights: spot under node2 (translated by (0,3,0) in node0's frame), directional under it rotated 45 deg about X
+    assert s.lights["light_type"].tolist() == [2, 0]
+    np.testing.assert_allclose(s.lights[0]["position"], xf(np.array([0, 3, 0])), atol=1e-5)
+    assert s.lights[0]["intensity"] == 3.0 and (int(s.lights[0]["range_packed"]) & 0xFFFF) == H.f16_bits(25.0)
+    assert int(s.lights[0]["cone_angles_packed"]) == H.f16_bits(0.2) | (H.f16_bits(0.6) << 16)
+    assert s.lights[1]["intensity"] == 2.0 and np.allclose(s.lights[1]["color"], [1.0, 0.9, 0.8])
+    np.testing.assert_allclose(np.linalg.norm(s.lights[1]["direction"]), 1.0, atol=1e-6)
+    # orthographic camera -> fov 45 (:243-245); direction / up are normalised although the node scales
+    cam = s.meta["cameras"][0]
+    assert cam["fov"] == 45.0
+    np.testing.assert_allclose(np.linalg.norm(cam["direction"]), 1.0, atol=1e-6)
+    np.testing.assert_allclose(cam["position"], xf(np.array([0.5, 0.25, 4.0])), atol=1e-5)
+    # scene selection: index 1 roots at node 0 directly (same geometry since node 3 is an identity wrapper)
+    assert host.load_gltf(os.path.join(GOLD, "modes.gltf"), 1).n_triangles == 14
+    with pytest.raises(host.GltfError, match="Scene 7 not found"):
+        host.load_gltf(os.path.join(GOLD, "modes.gltf"), 7)
+
+
+def test_loader_errors(tmp_path):
+    with pytest.raises(host.GltfError, match="IoError"):
+        host.load_gltf(str(tmp_path / "missing.gltf"))
+    bad = tmp_path / "bad.gltf"
+    bad.write_text("{ not json")
+    with pytest.raises(host.GltfError, match="GltfError"):
+        host.load_gltf(str(bad))
+    nopos = tmp_path / "nopos.gltf"
+    nopos.write_text('{"asset":{"version":"2.0"},"scenes":[{"nodes":[0]}],"nodes":[{"mesh":0}],"meshes":[{"primitives":[{"attributes":{}}]}]}')
+    with pytest.raises(host.GltfError, match="Primitive missing position data"):
+        host.load_gltf(str(nopos))
+    noscene = tmp_path / "noscene.gltf"
+    noscene.write_text('{"asset":{"version":"2.0"}}')
+    with pytest.raises(host.GltfError, match="No scenes found"):
+        host.load_gltf(str(noscene))
+    with pytest.raises(host.GltfError):
+        host.load_glb(b"glTF" + struct.pack("<II", 1, 12))
+
+
+def test_image_writers_round_trip(tmp_path):
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (37, 53, 4), dtype=np.uint8)
+    host.write_image(tmp_path / "a.ppm", img)
+    raw = (tmp_path / "a.ppm").read_bytes()
+    assert raw.startswith(b"P6\n53 37\n255\n")
+    np.testing.assert_array_equal(np.frombuffer(raw[len(b"P6\n53 37\n255\n"):], np.uint8).reshape(37, 53, 3), img[..., :3])
+    host.write_image(tmp_path / "a.png", img)
+    png = (tmp_path / "a.png").read_bytes()
+    assert png[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, hdr = 8, b"", None
+    while pos < len(png):
+        (n,), typ = struct.unpack(">I", png[pos:pos + 4]), png[pos + 4:pos + 8]
+        data = png[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", png[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(typ + data)
+        if typ == b"IHDR":
+            hdr = struct.unpack(">IIBBBBB", data)
+        if typ == b"IDAT":
+            idat += data
+        pos += 12 + n
+    assert hdr == (53, 37, 8, 6, 0, 0, 0)
+    rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(37, 1 + 53 * 4)
+    assert (rows[:, 0] == 0).all()
+    np.testing.assert_array_equal(rows[:, 1:].reshape(37, 53, 4), img)
+
+
+@pytest.mark.gpu
+def test_gltf_scene_through_the_whole_drop_in_path_on_gpu(gpu_ctx, oracle_mod, tmp_path):
+    """glTF file -> GltfLoader -> BvhBuilder -> BufferManager -> ComputeRenderer::run_compute (rt_dispatch_tile per tile
+    and channel) -> main_fs combine -> PNG; equals the oracle's frame of the same scene."""
+    scene = host.load_gltf(os.path.join(GOLD, "cornell12.gltf"))
+    w, h = 640, 360
+    n_dispatches, n_calls = host.render_progressive(gpu_ctx, scene, w, h)
+    assert n_dispatches == 5 * 3 * 3 and n_calls == 1  # 15 tiles <= 16: all in one run_compute call (TileHelper)
+    comb = gpu_ctx.read_rgba8_combined()
+    ref = oracle_mod.render_frame(oracle_mod.PackedScene(scene, use_bvh=False), w, h)
+    np.testing.assert_array_equal(comb, ref["combined"])
+    t = host.progressive_timing()
+    assert t["calls"] == 1 and t["tiles"] == 15 and t["total_ms"] > 0 and t["p50_ms"] <= t["p99_ms"] and t["tiles_per_s"] > 0
+    host.write_image(tmp_path / "cornell.png", comb)
+    assert (tmp_path / "cornell.png").stat().st_size > w * h * 4

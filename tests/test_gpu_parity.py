@@ -246,3 +246,22 @@ def test_full_size_properties_sponza_1080p(gpu_ctx):
     for c in range(3):
         np.testing.assert_array_equal(ch0[c][..., c], q[..., c])
         assert (ch0[c][..., 3] == 255).all() and (ch0[c][..., (c + 1) % 3] == 0).all()
+
+
+def test_bistro_like_vs_faithful_oracle(gpu_ctx, oracle_mod):
+    """3,800,000 triangles (BASELINE C4 stand-in): deep BVH, tiny-leaf foliage.  The oracle walks the reference's chunked
+    BVH (380-triangle mesh-order leaves, src/bvh.rs:154-247); first-found = lowest triangle index, so the comparison is exact."""
+    scene = scenes.bistro_like()
+    w, h = 96, 54
+    ref = oracle_mod.render_frame(oracle_mod.PackedScene(scene), w, h, mode=1)
+    gpu = _render_gpu(gpu_ctx, scene, w, h, mode=1)
+    _assert_bit_exact(gpu, ref)
+    st = gpu["stats"]
+    assert st["bvh_depth"] <= 32 and st["bvh_nodes"] > 500_000
+    # full-size properties at 4K: idempotent, finite, most of the street block is covered
+    gpu_ctx.render(3840, 2160, scene.camera, mode=1)
+    a = gpu_ctx.read_rgb32f()
+    prim, t = gpu_ctx.read_hits()
+    gpu_ctx.render(3840, 2160, scene.camera, mode=1)
+    np.testing.assert_array_equal(gpu_ctx.read_rgb32f().view(np.uint32), a.view(np.uint32))
+    assert np.isfinite(a).all() and (prim != 0xFFFFFFFF).mean() > 0.5
