@@ -282,11 +282,15 @@ __global__ __launch_bounds__(WAVE, RT_SM_MIN_WAVES) void k_render_extended_sm(De
     FilterRay fray;
     fray.o = sum;
     fray.inv = sum;
+    fray.err = sum;
     Hit hit;
     hit.t = RT_F32_MAX;
     hit.prim = RT_PRIM_MISS;
     hit.slot = 0;
-    uint32_t cur = REF_NONE, pleaf = REF_NONE;
+    uint32_t cur = REF_NONE;
+#if RT_SM_SPECULATIVE
+    uint32_t pleaf = REF_NONE;
+#endif
     int sp = 0;
     bool anyhit = false;
 
@@ -302,7 +306,9 @@ __global__ __launch_bounds__(WAVE, RT_SM_MIN_WAVES) void k_render_extended_sm(De
         test_spheres(sc, so, sd, hit);
         sp = 0;
         cur = sc.root_ref;
+#if RT_SM_SPECULATIVE
         pleaf = REF_NONE;
+#endif
         const bool finished = sc.n_tris == 0 || (any && hit.prim != RT_PRIM_MISS);
         state = finished ? (any ? ST_SHADOW_DONE : ST_CLOSEST_DONE) : ST_TRAVERSING;
     };
