@@ -205,7 +205,7 @@ void put_tri(const BuildTri& t, DevTri* o) {
     }
     o->material_id = t.material_id;
     o->prim_id = t.prim_id;
-    o->_pad = 0;
+    o->leaf_count = 0;
 }
 
 } // namespace
@@ -215,7 +215,7 @@ void build_bvh(const BuildTri* tris_in, size_t n_in, const BvhBuildOptions& opt_
     Builder b;
     b.opt = opt_in;
     if (b.opt.max_leaf < 1) b.opt.max_leaf = 1;
-    if (b.opt.max_leaf > 4) b.opt.max_leaf = 4; // the node format stores (count - 1) of a leaf child in 2 bits
+    if (b.opt.max_leaf > RT_DEV_MAX_LEAF_TRIS) b.opt.max_leaf = RT_DEV_MAX_LEAF_TRIS; // leaf offsets inside a node are 4-bit: 3 * 4 <= 15
     if (b.opt.max_depth > RT_DEV_MAX_BVH_DEPTH) b.opt.max_depth = RT_DEV_MAX_BVH_DEPTH;
     int hw = (int)std::thread::hardware_concurrency();
     b.max_tasks = std::max(1, (b.opt.threads > 0 ? b.opt.threads : (hw > 0 ? hw : 1)) - 1);
@@ -250,12 +250,13 @@ void build_bvh(const BuildTri* tris_in, size_t n_in, const BvhBuildOptions& opt_
     auto emit_leaf_tris = [&](const TmpNode& t) { // returns the first slot
         size_t first = tri_cursor;
         for (uint32_t i = 0; i < t.count; i++) put_tri(tris_in[b.ids[t.start + i]], &out.tris[tri_cursor++]);
+        out.tris[first].leaf_count = t.count; // the leaf test reads the run length from the first record
         return (uint32_t)first;
     };
     const TmpNode& rt_node = b.nodes[root];
     if (is_leaf(root)) { // whole scene fits one leaf
         uint32_t first = emit_leaf_tris(rt_node);
-        out.root_ref = RT_DEV_LEAF_FLAG | (rt_node.count << RT_DEV_LEAF_COUNT_SHIFT) | first;
+        out.root_ref = RT_DEV_LEAF_FLAG | first;
         out.n_leaves = 1;
         out.depth = 0;
         return;
@@ -301,11 +302,12 @@ void build_bvh(const BuildTri* tris_in, size_t n_in, const BvhBuildOptions& opt_
         const uint32_t node_base = (uint32_t)out.nodes.size();
         for (int c = 0; c < n_inner; c++) out.nodes.emplace_back();
         const uint32_t tri_base = (uint32_t)tri_cursor;
-        uint32_t cnt_bits = 0;
+        uint32_t child_off = 0; // 4 bits per child slot: i for inner child i, first triangle - tri_base for a leaf
+        for (int c = 0; c < n_inner; c++) child_off |= (uint32_t)c << (4 * c);
         for (int c = n_inner; c < nch; c++) {
             const TmpNode& lf = b.nodes[ordered[c]];
-            emit_leaf_tris(lf);
-            cnt_bits |= ((lf.count - 1u) & 3u) << (2 * (c - n_inner));
+            const uint32_t first = emit_leaf_tris(lf);
+            child_off |= ((first - tri_base) & 15u) << (4 * c);
             out.n_leaves++;
             if (root_area > 0) cost += opt_in.cost_intersect * lf.count * lf.box.half_area() / root_area;
         }
@@ -348,9 +350,9 @@ void build_bvh(const BuildTri* tris_in, size_t n_in, const BvhBuildOptions& opt_
             d.qlo[a] = lo_word;
             d.qhi[a] = hi_word;
         }
-        d.ex_cnt = ex[0] | (ex[1] << 8) | (ex[2] << 16) | (cnt_bits << 24);
-        d.base_inf = (node_base & RT_DEV_NODE_BASE_MASK) | ((uint32_t)n_inner << 26) | ((uint32_t)nch << 29);
-        d.tri_base = tri_base;
+        d.ex_off = ex[0] | (ex[1] << 8) | (ex[2] << 16) | ((child_off & 0xFFu) << 24);
+        d.base_off = (node_base & RT_DEV_NODE_BASE_MASK) | ((child_off >> 8) << 24);
+        d.tri_inf = (tri_base & RT_DEV_TRI_BASE_MASK) | ((uint32_t)n_inner << 27);
     }
     out.root_ref = 0;
     out.sah_cost = cost;

@@ -27,7 +27,7 @@ struct BuildTri {
 struct BvhBuild {
     std::vector<DevNode4> nodes;
     std::vector<DevTri> tris; // leaf order
-    uint32_t root_ref = RT_DEV_LEAF_FLAG; // empty leaf
+    uint32_t root_ref = RT_DEV_REF_NONE; // nothing to visit
     uint32_t depth = 0;                   // inner-node levels of the 4-wide tree on the longest root-to-leaf path
     uint32_t n_leaves = 0;
     double sah_cost = 0.0;

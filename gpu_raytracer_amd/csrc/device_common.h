@@ -104,22 +104,27 @@ __device__ __forceinline__ void test_spheres(const DevScene& sc, V3 o, V3 d, Hit
 // src/bvh.rs:154-247) and its brute-force path (shader/src/lib.rs:283) do, and makes the
 // result independent of our own topology.
 // ------------------------------------------------------------------------------------
-__device__ __forceinline__ void test_triangle(const DevTri* __restrict__ tris, uint32_t slot, V3 o, V3 d, Hit& hit) {
+// Returns the record's leaf_count word (the run length when `slot` is the first triangle of a leaf).
+__device__ __forceinline__ uint32_t test_triangle(const DevTri* __restrict__ tris, uint32_t slot, V3 o, V3 d, Hit& hit) {
     const float4* p = reinterpret_cast<const float4*>(tris + slot);
     float4 q0 = p[0], q1 = p[1], q2 = p[2];
+    // one 48-byte record = three 16-byte loads issued together (otherwise the compiler splits them by first use
+    // and sinks the later words behind the early-outs: more, and dependent, fetches)
+    asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w), "+v"(q2.x), "+v"(q2.y), "+v"(q2.z), "+v"(q2.w));
+    const uint32_t leaf_count = __float_as_uint(q2.w);
     V3 v0 = v3(q0.x, q0.y, q0.z);
     V3 e1 = v3(q0.w, q1.x, q1.y);
     V3 e2 = v3(q1.z, q1.w, q2.x);
     V3 h = cross(d, e2);
     float a = dot(e1, h);
-    if (fabsf(a) < RT_MIN_RAY_DISTANCE) return;
+    if (fabsf(a) < RT_MIN_RAY_DISTANCE) return leaf_count;
     float f = 1.0f / a;
     V3 s = o - v0;
     float u = f * dot(s, h);
-    if (u < 0.0f || u > 1.0f) return;
+    if (u < 0.0f || u > 1.0f) return leaf_count;
     V3 q = cross(s, e1);
     float v = f * dot(d, q);
-    if (v < 0.0f || u + v > 1.0f) return;
+    if (v < 0.0f || u + v > 1.0f) return leaf_count;
     float t = f * dot(e2, q);
     uint32_t prim = __float_as_uint(q2.z);
     if (t > RT_MIN_RAY_DISTANCE && (t < hit.t || (t == hit.t && prim < hit.prim))) {
@@ -127,6 +132,21 @@ __device__ __forceinline__ void test_triangle(const DevTri* __restrict__ tris, u
         hit.prim = prim;
         hit.slot = slot;
     }
+    return leaf_count;
+}
+
+// All triangles of the leaf `ref`.  ANY_HIT: stop at the first accepted one and return true.
+template <bool COUNT, bool ANY_HIT>
+__device__ __forceinline__ bool test_leaf(const DevTri* __restrict__ tris, uint32_t ref, V3 o, V3 d, Hit& hit, Counts& cnt) {
+    const uint32_t start = ref & RT_DEV_LEAF_START_MASK;
+    uint32_t n = 1;
+    for (uint32_t i = 0; i < n; i++) {
+        if (COUNT) cnt.tris++;
+        const uint32_t lc = test_triangle(tris, start + i, o, d, hit);
+        if (i == 0) n = lc;
+        if (ANY_HIT && hit.prim != RT_PRIM_MISS) return true;
+    }
+    return false;
 }
 
 // ------------------------------------------------------------------------------------
@@ -170,21 +190,11 @@ __device__ __forceinline__ FilterRay make_filter_ray(V3 o, V3 d) {
     return f;
 }
 
-#define RT_SWAP_IF(cond, ta, tb, ra, rb) \
-    {                                    \
-        const bool c_ = (cond);          \
-        const float tt_ = c_ ? tb : ta;  \
-        tb = c_ ? ta : tb;               \
-        ta = tt_;                        \
-        const uint32_t rr_ = c_ ? rb : ra; \
-        rb = c_ ? ra : rb;               \
-        ra = rr_;                        \
-    }
-
 // Per-lane stack access.  LDS_N == 0: every entry lives in LDS (lane-interleaved).  LDS_N > 0: entries below LDS_N
 // live in LDS, deeper ones in a global overflow area (also lane-interleaved): measured on the sponza-like and
 // bistro-like scenes the stack never exceeds 20 entries and is deeper than 16 in < 0.001 % of the visits, so a
-// 16-entry LDS part costs 4 KB per wave instead of (3 * depth + 4) * 256 B and more than doubles the waves per CU.
+// short LDS part costs ~4 KB per wave instead of (3 * depth + 4) * 256 B and more than doubles the waves per CU.
+// Callers test wave-wide whether any lane is near the LDS limit and take the branch-free LDS-only path if none is.
 template <int LDS_N>
 __device__ __forceinline__ void stack_store(uint32_t* __restrict__ lds, uint32_t* __restrict__ ovf, int k, uint32_t v) {
     if (LDS_N == 0 || k < LDS_N) lds[k * WAVE] = v;
@@ -195,78 +205,111 @@ __device__ __forceinline__ uint32_t stack_load(const uint32_t* __restrict__ lds,
     if (LDS_N == 0 || k < LDS_N) return lds[k * WAVE];
     return ovf[(k - LDS_N) * WAVE];
 }
+// pop for a whole wave: `sp` already decremented in the lanes where `want` holds
+template <int LDS_N>
+__device__ __forceinline__ uint32_t stack_pop(const uint32_t* __restrict__ lds, const uint32_t* __restrict__ ovf, int sp) {
+    if (LDS_N == 0 || __ballot(sp >= LDS_N) == 0ull) return lds[sp * WAVE];
+    return stack_load<LDS_N>(lds, ovf, sp);
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define RT_KEY_MASK 0x7FFFFFFCu /* entry distance (non-negative float bits) with the two low mantissa bits replaced by the child slot */
+#define RT_KEY_MISS 0x7F7FFFFCu /* F32_MAX & RT_KEY_MASK: keys at or above it are children the ray does not enter */
+#define RT_KEY_SORT2(a, b)            \
+    {                                 \
+        const uint32_t lo_ = min(a, b); \
+        b = max(a, b);                \
+        a = lo_;                      \
+    }
 
 // One visit of inner node `cur`.  Updates cur / the stack; returns false when the walk is exhausted.
 template <bool COUNT, int LDS_N = 0>
-__device__ __forceinline__ bool visit_node4(const uint4* __restrict__ nodes, uint32_t stack_entries, const FilterRay& fr, float closest_t,
-                                            uint32_t* __restrict__ stack, int& sp, uint32_t& cur, Counts& cnt,
-                                            uint32_t* __restrict__ ovf = nullptr) {
+__device__ __forceinline__ bool visit_node4(const uint4* __restrict__ nodes, const FilterRay& fr, float closest_t, uint32_t* __restrict__ stack,
+                                            int& sp, uint32_t& cur, Counts& cnt, uint32_t* __restrict__ ovf = nullptr) {
     const uint4* n = nodes + (size_t)cur * 3;
     const uint4 w0 = n[0], w1 = n[1], w2 = n[2];
     if (COUNT) cnt.nodes++;
-    const float scx = __uint_as_float((w0.w & 0xFFu) << 23), scy = __uint_as_float(((w0.w >> 8) & 0xFFu) << 23),
-                scz = __uint_as_float(((w0.w >> 16) & 0xFFu) << 23);
+    const float scx = __uint_as_float((w0.w << 23) & 0x7F800000u), scy = __uint_as_float((w0.w << 15) & 0x7F800000u),
+                scz = __uint_as_float((w0.w << 7) & 0x7F800000u);
     const float dox = __uint_as_float(w0.x) - fr.o.x, doy = __uint_as_float(w0.y) - fr.o.y, doz = __uint_as_float(w0.z) - fr.o.z;
     const float ax = scx * fr.inv.x, ay = scy * fr.inv.y, az = scz * fr.inv.z;
     const float bx = dox * fr.inv.x, by = doy * fr.inv.y, bz = doz * fr.inv.z;
     const float ex = fmaf(255.0f, scx, fabsf(dox)) * fr.err.x; // fr.err = RT_FILTER_SLACK * |inv|
     const float ey = fmaf(255.0f, scy, fabsf(doy)) * fr.err.y;
     const float ez = fmaf(255.0f, scz, fabsf(doz)) * fr.err.z;
-    const float bnx = bx - ex, bfx = bx + ex, bny = by - ey, bfy = by + ey, bnz = bz - ez, bfz = bz + ez;
+    // (near, far) pairs: one packed fma per child and axis
+    const f32x2 bx2 = {bx - ex, bx + ex}, by2 = {by - ey, by + ey}, bz2 = {bz - ez, bz + ez};
+    const f32x2 ax2 = {ax, ax}, ay2 = {ay, ay}, az2 = {az, az};
     // entry planes are the lower ones along axes the ray travels in +, the upper ones otherwise
     const bool px = fr.inv.x >= 0.0f, py = fr.inv.y >= 0.0f, pz = fr.inv.z >= 0.0f;
     const uint32_t nxw = px ? w1.z : w2.y, fxw = px ? w2.y : w1.z; // w1.z qlo_x, w2.y qhi_x
     const uint32_t nyw = py ? w1.w : w2.z, fyw = py ? w2.z : w1.w; // w1.w qlo_y, w2.z qhi_y
     const uint32_t nzw = pz ? w2.x : w2.w, fzw = pz ? w2.w : w2.x; // w2.x qlo_z, w2.w qhi_z
     const float limit = closest_t * 1.0000153f; // culling with slack, so equal-t candidates are still visited
-    float t[4];
+    uint32_t k[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const float tnx = fmaf((float)((nxw >> (8 * i)) & 0xFFu), ax, bnx), tfx = fmaf((float)((fxw >> (8 * i)) & 0xFFu), ax, bfx);
-        const float tny = fmaf((float)((nyw >> (8 * i)) & 0xFFu), ay, bny), tfy = fmaf((float)((fyw >> (8 * i)) & 0xFFu), ay, bfy);
-        const float tnz = fmaf((float)((nzw >> (8 * i)) & 0xFFu), az, bnz), tfz = fmaf((float)((fzw >> (8 * i)) & 0xFFu), az, bfz);
-        const float tmin = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
-        const float tmax = fminf(fminf(tfx, tfy), fminf(tfz, limit));
-        t[i] = (tmin <= tmax) ? tmin : RT_F32_MAX; // absent children are inverted boxes: never hit
+        const f32x2 qx = {(float)((nxw >> (8 * i)) & 0xFFu), (float)((fxw >> (8 * i)) & 0xFFu)};
+        const f32x2 qy = {(float)((nyw >> (8 * i)) & 0xFFu), (float)((fyw >> (8 * i)) & 0xFFu)};
+        const f32x2 qz = {(float)((nzw >> (8 * i)) & 0xFFu), (float)((fzw >> (8 * i)) & 0xFFu)};
+        const f32x2 tx = __builtin_elementwise_fma(qx, ax2, bx2);
+        const f32x2 ty = __builtin_elementwise_fma(qy, ay2, by2);
+        const f32x2 tz = __builtin_elementwise_fma(qz, az2, bz2);
+        const float tmin = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, 0.0f));
+        const float tmax = fminf(fminf(tx.y, ty.y), fminf(tz.y, limit));
+        const float t = (tmin <= tmax) ? tmin : RT_F32_MAX; // absent children are inverted boxes: never entered
+        k[i] = (__float_as_uint(t) & RT_KEY_MASK) | (uint32_t)i;
     }
-    // child references: inner children first (node_base + i), then leaves (consecutive triangle runs)
-    const uint32_t node_base = w1.x & RT_DEV_NODE_BASE_MASK, n_inner = (w1.x >> 26) & 7u;
-    const uint32_t cb = w0.w >> 24; // (count - 1) of leaf child j in bits 2j..2j+1
-    const uint32_t c0 = (cb & 3u) + 1u, c1 = ((cb >> 2) & 3u) + 1u, c2 = ((cb >> 4) & 3u) + 1u, c3 = ((cb >> 6) & 3u) + 1u;
-    const uint32_t l0 = RT_DEV_LEAF_FLAG | (c0 << RT_DEV_LEAF_COUNT_SHIFT) | w1.y;
-    const uint32_t l1 = RT_DEV_LEAF_FLAG | (c1 << RT_DEV_LEAF_COUNT_SHIFT) | (w1.y + c0);
-    const uint32_t l2 = RT_DEV_LEAF_FLAG | (c2 << RT_DEV_LEAF_COUNT_SHIFT) | (w1.y + c0 + c1);
-    const uint32_t l3 = RT_DEV_LEAF_FLAG | (c3 << RT_DEV_LEAF_COUNT_SHIFT) | (w1.y + c0 + c1 + c2);
-    uint32_t r0, r1, r2, r3; // leaf j is child n_inner + j
-    r0 = n_inner > 0u ? node_base : l0;
-    r1 = n_inner > 1u ? node_base + 1u : (n_inner == 1u ? l0 : l1);
-    r2 = n_inner > 2u ? node_base + 2u : (n_inner == 2u ? l0 : (n_inner == 1u ? l1 : l2));
-    r3 = n_inner > 3u ? node_base + 3u : (n_inner == 3u ? l0 : (n_inner == 2u ? l1 : (n_inner == 1u ? l2 : l3)));
-    float t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
-    // sort the four (distance, reference) pairs by distance: misses (F32_MAX) end up last.  (Leaving any-hit walks
-    // unsorted saves the exchanges but visits 4 % more nodes: no gain measured.)
-    RT_SWAP_IF(t1 < t0, t0, t1, r0, r1)
-    RT_SWAP_IF(t3 < t2, t2, t3, r2, r3)
-    RT_SWAP_IF(t2 < t0, t0, t2, r0, r2)
-    RT_SWAP_IF(t3 < t1, t1, t3, r1, r3)
-    RT_SWAP_IF(t2 < t1, t1, t2, r1, r2)
-    if (t0 == RT_F32_MAX) { // nothing hit: continue with the stack
+    // keep the node's three 16-byte loads together (the reference words are only used after the sort; without
+    // this the compiler sinks their load into the branch below, a fourth and dependent fetch)
+    uint32_t w1x = w1.x, w1y = w1.y;
+    asm volatile("" : "+v"(w1x), "+v"(w1y));
+    // sort the four keys: children the ray does not enter end up last.  (The order among children whose entry
+    // distances agree to 2 ulp is arbitrary: result-neutral, ties between HITS are resolved by triangle index.)
+    uint32_t k0 = k[0], k1 = k[1], k2 = k[2], k3 = k[3];
+    RT_KEY_SORT2(k0, k1)
+    RT_KEY_SORT2(k2, k3)
+    RT_KEY_SORT2(k0, k2)
+    RT_KEY_SORT2(k1, k3)
+    RT_KEY_SORT2(k1, k2)
+    if (k0 >= RT_KEY_MISS) { // nothing entered: continue with the stack
         if (sp == 0) return false;
         sp--;
-        cur = stack_load<LDS_N>(stack, ovf, sp);
+        cur = stack_pop<LDS_N>(stack, ovf, sp);
         return true;
     }
+    // child references from the sorted slots: base + 4-bit offset
+    const uint32_t child_off = (w0.w >> 24) | ((w1x >> 16) & 0xFF00u);
+    const uint32_t base_inner = w1x & RT_DEV_NODE_BASE_MASK;
+    const uint32_t base_leaf = (w1y & RT_DEV_TRI_BASE_MASK) | RT_DEV_LEAF_FLAG;
+    const uint32_t n_inner4 = (w1y >> 25) & 0x1Cu; // 4 * n_inner
+#define RT_CHILD_REF(key, out)                                                            \
+    {                                                                                     \
+        const uint32_t sh_ = ((key) << 2) & 12u;                                          \
+        out = (sh_ < n_inner4 ? base_inner : base_leaf) + ((child_off >> sh_) & 15u);     \
+    }
+    // push the other entered children far-to-near without branching: always store three words (the launch
+    // provides three spare entries), advance the pointer by the number of real ones
+    const int extra = (k1 < RT_KEY_MISS ? 1 : 0) + (k2 < RT_KEY_MISS ? 1 : 0) + (k3 < RT_KEY_MISS ? 1 : 0);
+    const uint32_t ek0 = extra == 3 ? k3 : (extra == 2 ? k2 : k1);
+    const uint32_t ek1 = extra == 3 ? k2 : k1;
+    uint32_t r0, e0, e1, r1;
+    RT_CHILD_REF(k0, r0)
+    RT_CHILD_REF(ek0, e0)
+    RT_CHILD_REF(ek1, e1)
+    RT_CHILD_REF(k1, r1)
+#undef RT_CHILD_REF
     cur = r0;
-    // push the other hits far-to-near without branching: always store three words (the launch provides three
-    // spare entries), advance the pointer by the number of real ones
-    const int extra = (t1 != RT_F32_MAX ? 1 : 0) + (t2 != RT_F32_MAX ? 1 : 0) + (t3 != RT_F32_MAX ? 1 : 0);
-    const uint32_t e0 = extra == 3 ? r3 : (extra == 2 ? r2 : r1);
-    const uint32_t e1 = extra == 3 ? r2 : r1;
-    stack_store<LDS_N>(stack, ovf, sp, e0);
-    stack_store<LDS_N>(stack, ovf, sp + 1, e1);
-    stack_store<LDS_N>(stack, ovf, sp + 2, r1);
+    if (LDS_N == 0 || __ballot(sp + 3 > LDS_N) == 0ull) {
+        stack[sp * WAVE] = e0;
+        stack[(sp + 1) * WAVE] = e1;
+        stack[(sp + 2) * WAVE] = r1;
+    } else {
+        stack_store<LDS_N>(stack, ovf, sp, e0);
+        stack_store<LDS_N>(stack, ovf, sp + 1, e1);
+        stack_store<LDS_N>(stack, ovf, sp + 2, r1);
+    }
     sp += extra;
-    (void)stack_entries;
     return true;
 }
 
@@ -280,16 +323,10 @@ __device__ __forceinline__ void traverse(const DevScene& sc, V3 o, V3 d, uint32_
     int sp = 0;
     for (;;) {
         if (!(cur & RT_DEV_LEAF_FLAG)) {
-            if (!visit_node4<COUNT>(nodes, sc.stack_entries, fr, hit.t, stack, sp, cur, cnt)) break;
+            if (!visit_node4<COUNT>(nodes, fr, hit.t, stack, sp, cur, cnt)) break;
             continue;
         }
-        uint32_t start = cur & RT_DEV_LEAF_START_MASK;
-        uint32_t count = (cur >> RT_DEV_LEAF_COUNT_SHIFT) & 0xFu;
-        for (uint32_t i = 0; i < count; i++) {
-            if (COUNT) cnt.tris++;
-            test_triangle(sc.tris, start + i, o, d, hit);
-            if (ANY_HIT && hit.prim != RT_PRIM_MISS) return;
-        }
+        if (test_leaf<COUNT, ANY_HIT>(sc.tris, cur, o, d, hit, cnt)) return;
         if (sp == 0) break;
         sp--;
         cur = stack[sp * WAVE];

@@ -12,7 +12,7 @@
 //            traversal is bound by vector-memory instructions per segment, so fewer and narrower
 //            node fetches are what pays.  Quantised boxes are supersets of the exact ones: they
 //            only filter, every hit is decided by the triangle test, results are unchanged.
-//            Leaves have no node record: a leaf is a (start,count) run of the triangle array.
+//            Leaves have no node record: a leaf is a run of the triangle array (length in its first record).
 //   DevTri   48 B, pre-gathered (v0, e1 = v1-v0, e2 = v2-v0, material, original
 //            index) stored in leaf order: one contiguous 48-byte read (3 x dwordx4)
 //            per triangle test.  e1/e2 are the same f32 subtractions the reference
@@ -23,9 +23,9 @@
 #include <stdint.h>
 
 #define RT_DEV_LEAF_FLAG 0x80000000u
-#define RT_DEV_LEAF_COUNT_SHIFT 27
-#define RT_DEV_LEAF_START_MASK 0x07FFFFFFu
-#define RT_DEV_MAX_LEAF_TRIS 15u
+#define RT_DEV_LEAF_START_MASK 0x7FFFFFFFu
+#define RT_DEV_REF_NONE 0xFFFFFFFFu /* "nothing to visit" (a leaf reference no tree contains) */
+#define RT_DEV_MAX_LEAF_TRIS 4u
 #define RT_DEV_MAX_TRIS 0x07FFFFFFu
 #define RT_DEV_MAX_BVH_DEPTH 32 /* binary build depth bound; the 4-wide tree is at most this deep */
 /* A visit of a 4-wide node pushes at most 3 references, so a tree of depth D needs 3*D + 1 stack entries per lane.
@@ -36,25 +36,32 @@
 #define RT_PRIM_SPHERE_FLAG 0x80000000u
 
 // Traversal references (stack entries, root_ref): bit 31 clear = inner node index;
-// bit 31 set = leaf: RT_DEV_LEAF_FLAG | count << 27 | first triangle.
+// bit 31 set = leaf: RT_DEV_LEAF_FLAG | first triangle.  The number of triangles of a leaf is stored in its
+// first triangle record (DevTri::leaf_count), which the leaf test loads anyway.
+//
+// A child reference is `base + offset`: the visit sorts 4 keys (entry distance with the child slot in the two
+// low mantissa bits, 10 integer min/max) and only then turns the up-to-four slots it needs into references:
+// offset = 4-bit field `slot` of child_off, base = node_base for slots < n_inner, LEAF | tri_base for the others.
 struct DevNode4 { // 48 bytes, 16-byte aligned
     float org[3];      // quantisation origin (the node's box minimum)
-    uint32_t ex_cnt;   // byte 0..2: exponent e of axis x,y,z (plane = org + q * 2^(e-127)); byte 3: (count-1) of leaf child j in bits 2j..2j+1
-    uint32_t base_inf; // bits 0..25 index of the first inner child (inner children are consecutive); 26..28 n_inner; 29..31 n_children
-    uint32_t tri_base; // first triangle of the first leaf child (leaf children's triangles are consecutive, in child order)
+    uint32_t ex_off;   // byte 0..2: exponent e of axis x,y,z (plane = org + q * 2^(e-127)); byte 3: offsets of child slots 0 (low nibble) and 1
+    uint32_t base_off; // bits 0..23 index of the first inner child (inner children are consecutive); byte 3: offsets of child slots 2 and 3
+    uint32_t tri_inf;  // bits 0..26 first triangle of the first leaf child (leaf children's triangles are consecutive, in child order); 27..29 n_inner
     uint32_t qlo[3];   // [axis]: byte i = quantised lower plane of child i (children: inner ones first, then leaves)
     uint32_t qhi[3];   // [axis]: byte i = quantised upper plane of child i; absent children are inverted (lo 255, hi 0)
 };
-#define RT_DEV_NODE_BASE_MASK 0x03FFFFFFu
-#define RT_DEV_MAX_NODES 0x03FFFFFFu
+// offset of child slot i: i for an inner child (node_base + i), the distance of a leaf's first triangle from tri_base otherwise (<= 12)
+#define RT_DEV_NODE_BASE_MASK 0x00FFFFFFu
+#define RT_DEV_MAX_NODES 0x00FFFFFFu
+#define RT_DEV_TRI_BASE_MASK 0x07FFFFFFu
 
 struct DevTri { // 48 bytes, 16-byte aligned
     float v0[3];
     float e1[3];
     float e2[3];
     uint32_t material_id;
-    uint32_t prim_id; // index in the caller's triangle array
-    uint32_t _pad;
+    uint32_t prim_id;    // index in the caller's triangle array
+    uint32_t leaf_count; // on the first triangle of a leaf: triangles in the leaf (1..4); 0 on the others
 };
 
 struct DevMaterial { // 32 bytes: the 8 words of Material the kernel reads (shader/src/material.rs:16-63), f16 fields decoded

@@ -253,7 +253,7 @@ __global__ __launch_bounds__(WAVE) void k_render_extended(DevScene sc, DevFrame 
 #ifndef RT_SM_LEAF_THRESHOLD
 #define RT_SM_LEAF_THRESHOLD 24
 #endif
-#define REF_NONE RT_DEV_LEAF_FLAG /* an empty leaf reference: "nothing to visit" */
+#define REF_NONE RT_DEV_REF_NONE
 #ifndef RT_SM_PARK_THRESHOLD
 #define RT_SM_PARK_THRESHOLD 8
 #endif
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(WAVE, RT_SM_MIN_WAVES) void k_render_extended_sm(De
                     dg_nl += __popcll(m_node);
                 }
                 if (can_node) {
-                    if (!visit_node4<COUNT>(nodes, sc.stack_entries, fray, hit.t, stack, sp, cur, cnt)) cur = REF_NONE;
+                    if (!visit_node4<COUNT>(nodes, fray, hit.t, stack, sp, cur, cnt)) cur = REF_NONE;
                 }
             } else if (m_leaf != 0ull) {
                 if (COUNT) {
@@ -520,12 +520,13 @@ __global__ __launch_bounds__(WAVE, RT_SM_MIN_WAVES) void k_render_extended_sm(De
                     dg_ll += __popcll(m_leaf);
                 }
                 if (has_leaf) {
-                    uint32_t start = pleaf & RT_DEV_LEAF_START_MASK;
-                    uint32_t count = (pleaf >> RT_DEV_LEAF_COUNT_SHIFT) & 0xFu;
+                    const uint32_t start = pleaf & RT_DEV_LEAF_START_MASK;
                     pleaf = REF_NONE;
-                    for (uint32_t i = 0; i < count; i++) {
+                    uint32_t n_tri = 1;
+                    for (uint32_t i = 0; i < n_tri; i++) {
                         if (COUNT) cnt.tris++;
-                        test_triangle(sc.tris, start + i, o, d, hit);
+                        const uint32_t lc = test_triangle(sc.tris, start + i, o, d, hit);
+                        if (i == 0) n_tri = lc;
                         if (anyhit && hit.prim != RT_PRIM_MISS) break;
                     }
                     if (anyhit && hit.prim != RT_PRIM_MISS) state = ST_SHADOW_DONE;
@@ -551,7 +552,7 @@ __global__ __launch_bounds__(WAVE, RT_SM_MIN_WAVES) void k_render_extended_sm(De
                     dg_nl += __popcll(wmask);
                 }
                 if (want) {
-                    if (!visit_node4<COUNT>(nodes, sc.stack_entries, fray, hit.t, stack, sp, cur, cnt))
+                    if (!visit_node4<COUNT>(nodes, fray, hit.t, stack, sp, cur, cnt))
                         state = anyhit ? ST_SHADOW_DONE : ST_CLOSEST_DONE;
                 }
             }
@@ -563,12 +564,14 @@ __global__ __launch_bounds__(WAVE, RT_SM_MIN_WAVES) void k_render_extended_sm(De
                 }
             }
             if (state == ST_TRAVERSING) { // cur is a leaf reference here
-                uint32_t start = cur & RT_DEV_LEAF_START_MASK;
-                uint32_t count = (cur >> RT_DEV_LEAF_COUNT_SHIFT) & 0xFu;
+                // `anyhit` differs between lanes, so one loop serves both kinds (any-hit lanes leave it at their first hit)
+                const uint32_t start = cur & RT_DEV_LEAF_START_MASK;
                 bool stop = false;
-                for (uint32_t i = 0; i < count; i++) {
+                uint32_t n_tri = 1;
+                for (uint32_t i = 0; i < n_tri; i++) {
                     if (COUNT) cnt.tris++;
-                    test_triangle(sc.tris, start + i, o, d, hit);
+                    const uint32_t lc = test_triangle(sc.tris, start + i, o, d, hit);
+                    if (i == 0) n_tri = lc;
                     if (anyhit && hit.prim != RT_PRIM_MISS) {
                         stop = true;
                         break;

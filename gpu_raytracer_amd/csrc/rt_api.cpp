@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -44,6 +45,7 @@ struct DeviceState {
     rt::WfBuffers wf{};                                    // wavefront pipeline state (extended mode)
     bool used_wavefront = false;
     uint32_t wf_lights = 0;
+    uint32_t wf_spp = 0; // spp the current wavefront allocation was sized for
     std::vector<void*> wf_allocs;
 };
 
@@ -202,6 +204,8 @@ int upload_common(rt_ctx* ctx, const rt_sphere* spheres, uint32_t n_spheres, con
     }
     rt::BvhBuild bvh;
     rt::BvhBuildOptions opt;
+    if (const char* e = std::getenv("RT_BVH_COST_TRAVERSE")) opt.cost_traverse = (float)std::atof(e); // tuning knobs (development)
+    if (const char* e = std::getenv("RT_BVH_MAX_LEAF")) opt.max_leaf = (uint32_t)std::atoi(e);
     double t0 = now_ms();
     rt::build_bvh(bt.data(), bt.size(), opt, bvh);
     double build_ms = now_ms() - t0;
@@ -304,7 +308,7 @@ int ensure_wavefront(rt_ctx* ctx, DeviceState& d, uint32_t n_blocks, uint32_t ba
     HIPCHK(ctx, alloc((void**)&w.q_vtx, 16));
     HIPCHK(ctx, alloc((void**)&w.q_shadow, (P * (size_t)std::max(1u, n_lights) + pad_shadow) * 4));
     HIPCHK(ctx, alloc((void**)&w.counters, rt::WF_N_COUNTERS * sizeof(uint32_t)));
-    HIPCHK(ctx, alloc((void**)&w.totals, 8 * sizeof(unsigned long long)));
+    HIPCHK(ctx, alloc((void**)&w.totals, 16 * sizeof(unsigned long long)));
     HIPCHK(ctx, alloc((void**)&w.accum, (size_t)std::max(1u, n_blocks) * 64 * 16));
     HIPCHK(ctx, alloc((void**)&w.stack_ovf, (size_t)rt::wf_persistent_waves() * ovf_entries * 64 * 4));
     w.ovf_entries = ovf_entries;
@@ -315,15 +319,28 @@ int ensure_wavefront(rt_ctx* ctx, DeviceState& d, uint32_t n_blocks, uint32_t ba
     return RT_OK;
 }
 
-// Samples per pixel kept in flight by the wavefront pipeline: as many as fit ~8M paths (RT_WF_BATCH overrides).
-uint32_t wavefront_batch(uint32_t n_blocks, uint32_t spp) {
-    uint32_t want = 0;
-    if (const char* e = std::getenv("RT_WF_BATCH")) want = (uint32_t)std::strtoul(e, nullptr, 10);
-    if (want == 0) {
-        const uint64_t target_paths = 8ull << 20;
-        want = (uint32_t)std::max<uint64_t>(1, target_paths / std::max<uint64_t>(1, (uint64_t)n_blocks * 64u));
+// Samples per pixel kept in flight by the wavefront pipeline.  Every stage of every bounce ends in a tail where
+// the persistent waves drain, and late bounces carry few paths, so batches should be as large as memory allows:
+// measured on the headline frame, 3 samples per batch (8 M paths) 4,640 Mrays/s, 32 per batch (71 M paths, 12 GB
+// of the 288 GB) 5,840.  Target 64 M paths, bounded by half the free device memory, the 27-bit path id of a shadow
+// queue entry and the 32-bit queue positions; the samples are then spread evenly over the batches.
+// RT_WF_BATCH (samples per batch) / RT_WF_TARGET_PATHS override.
+uint32_t wavefront_batch(uint32_t n_blocks, uint32_t spp, uint32_t n_lights, size_t free_bytes) {
+    if (const char* e = std::getenv("RT_WF_BATCH")) {
+        const uint32_t want = (uint32_t)std::strtoul(e, nullptr, 10);
+        if (want) return std::max(1u, std::min(want, spp));
     }
-    return std::max(1u, std::min(want, spp));
+    uint64_t target_paths = 64ull << 20;
+    if (const char* e = std::getenv("RT_WF_TARGET_PATHS")) target_paths = std::max<uint64_t>(1, std::strtoull(e, nullptr, 10));
+    const uint64_t lights = std::max(1u, n_lights);
+    const uint64_t bytes_per_path = 8 * 16 + 4 + 4 + 2 * 4 + 4 * lights; // path state, vis, pxy, two extension queues, shadow queue
+    target_paths = std::min<uint64_t>(target_paths, free_bytes / 2 / bytes_per_path);
+    target_paths = std::min<uint64_t>(target_paths, (uint64_t)RT_WF_ID_MASK + 1);
+    target_paths = std::min<uint64_t>(target_paths, (1ull << 31) / lights);
+    const uint64_t per_sample = std::max<uint64_t>(1, (uint64_t)n_blocks * 64u);
+    const uint32_t max_batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(spp, target_paths / per_sample));
+    const uint32_t n_batches = (spp + max_batch - 1) / max_batch;
+    return std::max(1u, (spp + n_batches - 1) / std::max(1u, n_batches));
 }
 
 // Launch one frame (or one explicit tile) on every device and wait.
@@ -352,10 +369,14 @@ int run_frame(rt_ctx* ctx, DevFrame fr, bool counters, uint32_t world, uint32_t 
                                ctx->scene_counts.n_lights <= RT_WF_MAX_LIGHTS;
         if (wavefront) {
             const uint32_t n_blocks = f.n_owned_tiles * rt::blocks_per_tile(f.tile_size);
-            const uint32_t batch = wavefront_batch(n_blocks, f.spp);
+            size_t free_b = 0, total_b = 0;
+            HIPCHK(ctx, hipMemGetInfo(&free_b, &total_b));
+            const uint32_t batch = d.wf.n_blocks == n_blocks && d.wf_spp == f.spp && d.wf.batch && d.wf_lights >= ctx->scene_counts.n_lights ? d.wf.batch // same frame shape as last time: keep the allocation
+                                                                                               : wavefront_batch(n_blocks, f.spp, ctx->scene_counts.n_lights, free_b);
+            d.wf_spp = f.spp;
             rc = ensure_wavefront(ctx, d, n_blocks, batch, ctx->scene_counts.n_lights);
             if (rc != RT_OK) return rc;
-            HIPCHK(ctx, hipMemsetAsync(d.wf.totals, 0, 8 * sizeof(unsigned long long), d.stream));
+            HIPCHK(ctx, hipMemsetAsync(d.wf.totals, 0, 16 * sizeof(unsigned long long), d.stream));
             HIPCHK(ctx, hipEventRecord(d.ev0, d.stream)); // re-record: allocation above is not part of the kernel time
             const DevScene dsc = scene_for(ctx, d);
             for (uint32_t first = 0; first < f.spp; first += batch) {
@@ -392,7 +413,7 @@ int run_frame(rt_ctx* ctx, DevFrame fr, bool counters, uint32_t world, uint32_t 
         HIPCHK(ctx, hipEventElapsedTime(&ms, d.ev0, d.ev1));
         kernel_ms = std::max(kernel_ms, (double)ms);
         if (extended && d.used_wavefront) {
-            unsigned long long t[8];
+            unsigned long long t[16];
             HIPCHK(ctx, hipMemcpy(t, d.wf.totals, sizeof t, hipMemcpyDeviceToHost));
             cnt[0] += t[0] + t[1] + t[2];
             cnt[3] += t[0];
@@ -403,6 +424,7 @@ int run_frame(rt_ctx* ctx, DevFrame fr, bool counters, uint32_t world, uint32_t 
             cnt[8] = std::max(cnt[8], t[5]); // diagnostics: stack high-water mark, visits with > 16 / > 24 entries
             cnt[9] += t[6];
             cnt[10] += t[7];
+            for (int k = 0; k < 5; k++) cnt[11 + k] += t[8 + k]; // wave-level step counts of the traversal stages
         } else if (counters || extended) {
             unsigned long long c[16];
             HIPCHK(ctx, hipMemcpy(c, d.counters, sizeof c, hipMemcpyDeviceToHost));

@@ -36,7 +36,10 @@ using namespace rtdev;
 #ifndef RT_WF_WAVES_PER_CU
 #define RT_WF_WAVES_PER_CU 24
 #endif
-#define WF_REF_NONE RT_DEV_LEAF_FLAG /* empty leaf reference: nothing left to visit */
+#ifndef RT_WF_SHADOW_LIGHT_MAJOR
+#define RT_WF_SHADOW_LIGHT_MAJOR 1
+#endif
+#define WF_REF_NONE RT_DEV_REF_NONE /* nothing left to visit */
 
 namespace {
 
@@ -140,6 +143,7 @@ __global__ __launch_bounds__(WAVE, RT_WF_MIN_WAVES) void k_wf_trace(DevScene sc,
     Counts cnt = {0u, 0u};
     int sp_max = 0;
     uint32_t sp_gt16 = 0, sp_gt24 = 0;
+    uint32_t d_node_steps = 0, d_leaf_steps = 0, d_leaf_lanes = 0, d_leaf_trips = 0, d_refills = 0; // wave-uniform diagnostics (COUNT)
 
     bool active = false, exhausted = false;
     uint32_t chunk_next = 0, chunk_end = 0; // wave-uniform
@@ -171,6 +175,7 @@ __global__ __launch_bounds__(WAVE, RT_WF_MIN_WAVES) void k_wf_trace(DevScene sc,
                 if (base >= count) exhausted = true;
             }
             if (!exhausted) {
+                if (COUNT) d_refills++;
                 const uint32_t idx = chunk_next + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
                 chunk_next += (uint32_t)__popcll(idle);
                 uint32_t e = WF_SENTINEL;
@@ -212,7 +217,7 @@ __global__ __launch_bounds__(WAVE, RT_WF_MIN_WAVES) void k_wf_trace(DevScene sc,
                 pleaf = cur; // postpone the leaf, keep descending
                 if (sp > 0) {
                     sp--;
-                    cur = stack_load<RT_WF_LDS_STACK>(stack, ovf, sp);
+                    cur = stack_pop<RT_WF_LDS_STACK>(stack, ovf, sp);
                 } else {
                     cur = WF_REF_NONE;
                 }
@@ -221,8 +226,9 @@ __global__ __launch_bounds__(WAVE, RT_WF_MIN_WAVES) void k_wf_trace(DevScene sc,
             const bool has_leaf = active && pleaf != WF_REF_NONE;
             const unsigned long long m_node = __ballot(can_node), m_leaf = __ballot(has_leaf);
             if (m_node != 0ull && __popcll(m_leaf) < RT_WF_LEAF_THRESHOLD) {
+                if (COUNT) d_node_steps++;
                 if (can_node) {
-                    if (!visit_node4<COUNT, RT_WF_LDS_STACK>(nodes, sc.stack_entries, fray, hit.t, stack, sp, cur, cnt, ovf)) cur = WF_REF_NONE;
+                    if (!visit_node4<COUNT, RT_WF_LDS_STACK>(nodes, fray, hit.t, stack, sp, cur, cnt, ovf)) cur = WF_REF_NONE;
                     if (COUNT) {
                         sp_max = max(sp_max, sp);
                         sp_gt16 += sp > 16 ? 1u : 0u;
@@ -230,15 +236,19 @@ __global__ __launch_bounds__(WAVE, RT_WF_MIN_WAVES) void k_wf_trace(DevScene sc,
                     }
                 }
             } else if (m_leaf != 0ull) {
+                uint32_t trips = 0;
                 if (has_leaf) {
-                    const uint32_t start = pleaf & RT_DEV_LEAF_START_MASK, n_tri = (pleaf >> RT_DEV_LEAF_COUNT_SHIFT) & 0xFu;
+                    const uint32_t before = cnt.tris;
+                    const uint32_t leaf = pleaf;
                     pleaf = WF_REF_NONE;
-                    for (uint32_t i = 0; i < n_tri; i++) {
-                        if (COUNT) cnt.tris++;
-                        test_triangle(sc.tris, start + i, o, d, hit);
-                        if (ANY && hit.prim != RT_PRIM_MISS) break;
-                    }
-                    if (ANY && hit.prim != RT_PRIM_MISS) cur = WF_REF_NONE; // occluded: nothing more to do
+                    if (test_leaf<COUNT, ANY>(sc.tris, leaf, o, d, hit, cnt)) cur = WF_REF_NONE; // occluded: nothing more to do
+                    trips = cnt.tris - before;
+                }
+                if (COUNT) {
+                    d_leaf_steps++;
+                    d_leaf_lanes += (uint32_t)__popcll(m_leaf);
+                    for (int off = 32; off > 0; off >>= 1) trips = max(trips, (uint32_t)__shfl_xor((int)trips, off, WAVE));
+                    d_leaf_trips += trips;
                 }
             }
             if (active && cur == WF_REF_NONE && pleaf == WF_REF_NONE) { // segment finished
@@ -264,6 +274,11 @@ __global__ __launch_bounds__(WAVE, RT_WF_MIN_WAVES) void k_wf_trace(DevScene sc,
             atomicMax(&wb.totals[5], (unsigned long long)sp_max);
             atomicAdd(&wb.totals[6], g16);
             atomicAdd(&wb.totals[7], g24);
+            atomicAdd(&wb.totals[8], (unsigned long long)d_node_steps);
+            atomicAdd(&wb.totals[9], (unsigned long long)d_leaf_steps);
+            atomicAdd(&wb.totals[10], (unsigned long long)d_leaf_lanes);
+            atomicAdd(&wb.totals[11], (unsigned long long)d_leaf_trips);
+            atomicAdd(&wb.totals[12], (unsigned long long)d_refills);
         }
     }
 }
@@ -328,6 +343,23 @@ __global__ __launch_bounds__(256) void k_wf_shade(DevScene sc, DevFrame fr, rt::
                     if (contrib.x != 0.0f || contrib.y != 0.0f || contrib.z != 0.0f) mask |= 1u << li;
                 }
             }
+#if RT_WF_SHADOW_LIGHT_MAJOR
+            // light-major order inside the wave's slice: consecutive entries (one traversal wave's refill) go
+            // toward the same light from neighbouring vertices
+            uint32_t total = 0;
+            for (uint32_t li = 0; li < sc.n_lights; li++) total += (uint32_t)__popcll(__ballot((mask >> li) & 1u));
+            if (total) {
+                uint32_t at = window_reserve(wb.q_shadow, &wb.counters[rt::WF_SHADOW_COUNT], win, max((uint32_t)RT_WF_WINDOW, sc.n_lights * WAVE), 0u, 0u, total);
+                n_shadow += (uint32_t)__popc(mask);
+                const unsigned long long below = (1ull << (threadIdx.x & 63u)) - 1ull;
+                for (uint32_t li = 0; li < sc.n_lights; li++) {
+                    const bool want = (mask >> li) & 1u;
+                    const unsigned long long b = __ballot(want);
+                    if (want) wb.q_shadow[at + (uint32_t)__popcll(b & below)] = id | (li << 27);
+                    at += (uint32_t)__popcll(b);
+                }
+            }
+#else
             const uint32_t mine = (uint32_t)__popc(mask);
             const uint32_t incl = wave_incl_scan(mine), total = __shfl(incl, WAVE - 1, WAVE);
             if (total) {
@@ -339,6 +371,7 @@ __global__ __launch_bounds__(256) void k_wf_shade(DevScene sc, DevFrame fr, rt::
                     wb.q_shadow[at++] = id | (li << 27);
                 }
             }
+#endif
         }
     }
     window_close(wb.q_shadow, win);
