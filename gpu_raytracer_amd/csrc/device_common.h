@@ -175,6 +175,9 @@ __device__ __forceinline__ bool test_leaf(const DevTri* __restrict__ tris, uint3
 #ifndef RT_FILTER_SLACK
 #define RT_FILTER_SLACK 1.0e-6f
 #endif
+#ifndef RT_FILTER_RCP
+#define RT_FILTER_RCP 0
+#endif
 struct FilterRay { // per-segment constants of the box filter
     V3 o, inv;     // inv = 1/d with |d| clamped away from zero (a filter may do that; the triangle test uses the real d)
     V3 err;        // RT_FILTER_SLACK * |inv|: scale of the conservative widening, see visit_node4
@@ -185,7 +188,13 @@ __device__ __forceinline__ FilterRay make_filter_ray(V3 o, V3 d) {
     float dx = fabsf(d.x) < 1e-30f ? copysignf(1e-30f, d.x) : d.x;
     float dy = fabsf(d.y) < 1e-30f ? copysignf(1e-30f, d.y) : d.y;
     float dz = fabsf(d.z) < 1e-30f ? copysignf(1e-30f, d.z) : d.z;
+#if RT_FILTER_RCP
+    // v_rcp_f32 (1 ulp) instead of three IEEE divisions (~11 instructions each): the filter's error bound grows
+    // from 2^-22 to 2^-22 + 2^-23 relative, still far inside RT_FILTER_SLACK
+    f.inv = v3(__builtin_amdgcn_rcpf(dx), __builtin_amdgcn_rcpf(dy), __builtin_amdgcn_rcpf(dz));
+#else
     f.inv = v3(1.0f / dx, 1.0f / dy, 1.0f / dz);
+#endif
     f.err = v3(fabsf(f.inv.x) * RT_FILTER_SLACK, fabsf(f.inv.y) * RT_FILTER_SLACK, fabsf(f.inv.z) * RT_FILTER_SLACK);
     return f;
 }
@@ -407,6 +416,7 @@ __device__ __forceinline__ void hit_geometry(const DevScene& sc, const Hit& hit,
     } else {
         const float4* p = reinterpret_cast<const float4*>(sc.tris + hit.slot);
         float4 q0 = p[0], q1 = p[1], q2 = p[2];
+        asm volatile("" : "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w), "+v"(q2.x), "+v"(q2.y)); // one round trip for the record
         V3 e1 = v3(q0.w, q1.x, q1.y);
         V3 e2 = v3(q1.z, q1.w, q2.x);
         normal = normalize(cross(e1, e2)); // geometric, winding dependent, never flipped (intersection.rs:132)

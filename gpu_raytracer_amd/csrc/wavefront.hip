@@ -33,6 +33,12 @@ using namespace rtdev;
 #ifndef RT_WF_LEAF_THRESHOLD
 #define RT_WF_LEAF_THRESHOLD 24 /* lanes holding a postponed leaf before the triangle tests run */
 #endif
+#ifndef RT_WF_SHADE_WAVES
+#define RT_WF_SHADE_WAVES 4 /* waves per SIMD the shading stages are register-allocated for */
+#endif
+#ifndef RT_WF_LEAF_POLICY
+#define RT_WF_LEAF_POLICY 0 /* 0: triangle tests run when RT_WF_LEAF_THRESHOLD lanes hold a leaf; 1: when that many lanes are blocked on theirs */
+#endif
 #ifndef RT_WF_WAVES_PER_CU
 #define RT_WF_WAVES_PER_CU 24
 #endif
@@ -225,7 +231,12 @@ __global__ __launch_bounds__(WAVE, RT_WF_MIN_WAVES) void k_wf_trace(DevScene sc,
             const bool can_node = active && !(cur & RT_DEV_LEAF_FLAG);
             const bool has_leaf = active && pleaf != WF_REF_NONE;
             const unsigned long long m_node = __ballot(can_node), m_leaf = __ballot(has_leaf);
-            if (m_node != 0ull && __popcll(m_leaf) < RT_WF_LEAF_THRESHOLD) {
+#if RT_WF_LEAF_POLICY == 1
+            const unsigned long long m_gate = __ballot(has_leaf && !can_node); // lanes that cannot step before their leaf is tested
+#else
+            const unsigned long long m_gate = m_leaf;
+#endif
+            if (m_node != 0ull && __popcll(m_gate) < RT_WF_LEAF_THRESHOLD) {
                 if (COUNT) d_node_steps++;
                 if (can_node) {
                     if (!visit_node4<COUNT, RT_WF_LDS_STACK>(nodes, fray, hit.t, stack, sp, cur, cnt, ovf)) cur = WF_REF_NONE;
@@ -283,6 +294,32 @@ __global__ __launch_bounds__(WAVE, RT_WF_MIN_WAVES) void k_wf_trace(DevScene sc,
     }
 }
 
+// The shading stages are bound by memory latency, not arithmetic (22 % VALU busy, 83 % of the wave time in s_waitcnt):
+// what counts is the number of DEPENDENT round trips per path.  Lights come from LDS (staged once per block), and
+// each group of per-path loads is issued together: RT_KEEP_TOGETHER pins the loaded values at one point so the
+// compiler cannot split a record by first use and sink the later words behind a branch (each a further round trip).
+#define RT_KEEP4(v) asm volatile("" : "+v"((v).x), "+v"((v).y), "+v"((v).z), "+v"((v).w))
+__device__ __forceinline__ void stage_lights(DevLight* __restrict__ s_lights, const DevScene& sc) {
+    const uint32_t words = sc.n_lights * (uint32_t)(sizeof(DevLight) / 4);
+    const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(sc.lights);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(s_lights);
+    for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+}
+__device__ __forceinline__ DevMaterial load_material(const DevScene& sc, uint32_t material_id) {
+    const float4* p = reinterpret_cast<const float4*>(sc.materials + material_id);
+    float4 a = p[0], b = p[1];
+    RT_KEEP4(a);
+    RT_KEEP4(b);
+    DevMaterial m;
+    m.albedo[0] = a.x; m.albedo[1] = a.y; m.albedo[2] = a.z; m.metallic = a.w;
+    m.emission[0] = b.x; m.emission[1] = b.y; m.emission[2] = b.z; m.ior = b.w;
+    const float2 c = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(sc.materials + material_id) + 8);
+    m.transmission = c.x; m.roughness = c.y;
+    m._pad[0] = m._pad[1] = 0.0f;
+    return m;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // shading stage 1: consume the closest hit, store the vertex, enqueue shadow segments
 // ---------------------------------------------------------------------------------------------------------
@@ -290,39 +327,47 @@ __device__ __forceinline__ void wf_end_path(const rt::WfBuffers& wb, uint32_t id
     wb.sample_rad[id] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
 }
 
-__global__ __launch_bounds__(256) void k_wf_shade(DevScene sc, DevFrame fr, rt::WfBuffers wb, const uint32_t* __restrict__ queue) {
+__global__ __launch_bounds__(256, RT_WF_SHADE_WAVES) void k_wf_shade(DevScene sc, DevFrame fr, rt::WfBuffers wb, const uint32_t* __restrict__ queue) {
+    __shared__ DevLight s_lights[RT_WF_MAX_LIGHTS];
+    stage_lights(s_lights, sc);
     const uint32_t count = wb.counters[rt::WF_EXT_COUNT];
     const bool shadows = (fr.flags & 2u) == 0;
     const uint32_t stride = gridDim.x * blockDim.x;
     OutWindow win = {0u, 0u};
     uint32_t n_shadow = 0;
     // every wave runs the same number of iterations so the wave-aggregated appends see whole waves
+    uint32_t id_next = blockIdx.x * blockDim.x + threadIdx.x < count ? queue[blockIdx.x * blockDim.x + threadIdx.x] : WF_SENTINEL;
     for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += stride) {
-        const uint32_t i = base + threadIdx.x;
-        uint32_t id = i < count ? queue[i] : WF_SENTINEL;
+        const uint32_t id = id_next;
+        const uint32_t i_next = base + stride + threadIdx.x; // the next entry is fetched a whole iteration ahead
+        id_next = i_next < count ? queue[i_next] : WF_SENTINEL;
         const bool have = id != WF_SENTINEL;
         bool vertex = false;
         V3 point = v3(0, 0, 0), normal = point;
         uint32_t material_id = 0;
+        DevMaterial m = {};
         if (have) {
-            const uint4 h = wb.hit[id];
-            const float4 th = wb.thr[id], ra = wb.rad[id];
-            const V3 throughput = f4v(th);
-            V3 radiance = f4v(ra);
+            uint4 h = wb.hit[id];
+            float4 ro = wb.ray_o[id], rd = wb.ray_d[id];
+            asm volatile("" : "+v"(h.x), "+v"(h.y), "+v"(h.z));
+            RT_KEEP4(ro);
+            RT_KEEP4(rd);
+            // throughput / radiance are only read where a path ends here (a quarter of this stage's read traffic otherwise)
             if (h.y == RT_PRIM_MISS) { // process_wavefront_ray, wavefront.rs:146-151
-                radiance = radiance + v3(0.1f, 0.2f, 0.3f) * throughput;
+                const V3 radiance = f4v(wb.rad[id]) + v3(0.1f, 0.2f, 0.3f) * f4v(wb.thr[id]);
                 wf_end_path(wb, id, radiance);
             } else {
                 Hit hit;
                 hit.t = __uint_as_float(h.x);
                 hit.prim = h.y;
                 hit.slot = h.z;
-                hit_geometry(sc, hit, f4v(wb.ray_o[id]), f4v(wb.ray_d[id]), point, normal, material_id);
+                hit_geometry(sc, hit, f4v(ro), f4v(rd), point, normal, material_id);
                 if (material_id >= sc.n_materials) {
-                    radiance = radiance + v3(1.0f, 0.0f, 1.0f) * throughput;
+                    const V3 radiance = f4v(wb.rad[id]) + v3(1.0f, 0.0f, 1.0f) * f4v(wb.thr[id]);
                     wf_end_path(wb, id, radiance);
                 } else {
                     vertex = true;
+                    m = load_material(sc, material_id);
                     wb.vtx_p[id] = make_float4(point.x, point.y, point.z, __uint_as_float(material_id));
                     wb.vtx_n[id] = make_float4(normal.x, normal.y, normal.z, 0.0f);
                     wb.vis[id] = 0u;
@@ -335,11 +380,10 @@ __global__ __launch_bounds__(256) void k_wf_shade(DevScene sc, DevFrame fr, rt::
             // aggregated append per wave: exclusive scan of the per-lane counts + a single atomicAdd.
             uint32_t mask = 0;
             if (vertex) {
-                const DevMaterial m = sc.materials[material_id];
                 for (uint32_t li = 0; li < sc.n_lights; li++) {
                     V3 sdir;
                     float sdist;
-                    const V3 contrib = light_contribution(sc.lights[li], m, point, normal, sdir, sdist);
+                    const V3 contrib = light_contribution(s_lights[li], m, point, normal, sdir, sdist);
                     if (contrib.x != 0.0f || contrib.y != 0.0f || contrib.z != 0.0f) mask |= 1u << li;
                 }
             }
@@ -382,33 +426,47 @@ __global__ __launch_bounds__(256) void k_wf_shade(DevScene sc, DevFrame fr, rt::
 // ---------------------------------------------------------------------------------------------------------
 // shading stage 2: ordered light sum, terminal shading or continuation
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_wf_finish(DevScene sc, DevFrame fr, rt::WfBuffers wb, const uint32_t* __restrict__ queue,
+__global__ __launch_bounds__(256, RT_WF_SHADE_WAVES) void k_wf_finish(DevScene sc, DevFrame fr, rt::WfBuffers wb, const uint32_t* __restrict__ queue,
                                                   uint32_t* __restrict__ next_queue) {
+    __shared__ DevLight s_lights[RT_WF_MAX_LIGHTS];
+    stage_lights(s_lights, sc);
     const uint32_t count = wb.counters[rt::WF_EXT_COUNT];
     const bool shadows = (fr.flags & 2u) == 0;
     const uint32_t stride = gridDim.x * blockDim.x;
     OutWindow win = {0u, 0u};
     uint32_t n_cont = 0;
+    uint32_t id_next = blockIdx.x * blockDim.x + threadIdx.x < count ? queue[blockIdx.x * blockDim.x + threadIdx.x] : WF_SENTINEL;
     for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += stride) {
-        const uint32_t i = base + threadIdx.x;
         bool cont = false;
-        uint32_t id = 0;
+        const uint32_t id = id_next;
+        const uint32_t i_next = base + stride + threadIdx.x; // the next entry is fetched a whole iteration ahead
+        id_next = i_next < count ? queue[i_next] : WF_SENTINEL;
         float4 vp = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
-        if (i < count) id = queue[i];
-        else id = WF_SENTINEL;
-        if (id != WF_SENTINEL) vp = wb.vtx_p[id];
+        float4 vn = vp, th = vp, ra = vp, rdin = vp;
+        uint32_t vis = 0;
+        if (id != WF_SENTINEL) { // the whole path record in one round trip
+            vp = wb.vtx_p[id];
+            vn = wb.vtx_n[id];
+            th = wb.thr[id];
+            ra = wb.rad[id];
+            rdin = wb.ray_d[id];
+            vis = wb.vis[id];
+            RT_KEEP4(vp);
+            RT_KEEP4(vn);
+            RT_KEEP4(th);
+            RT_KEEP4(ra);
+            RT_KEEP4(rdin);
+            asm volatile("" : "+v"(vis));
+        }
         if (__float_as_uint(vp.w) != 0xFFFFFFFFu) { // paths that ended in k_wf_shade carry the "no vertex" marker
-
-            const V3 point = f4v(vp), normal = f4v(wb.vtx_n[id]);
+            const V3 point = f4v(vp), normal = f4v(vn);
             const uint32_t material_id = __float_as_uint(vp.w);
-            const DevMaterial m = sc.materials[material_id];
-            const float4 th = wb.thr[id], ra = wb.rad[id];
+            const DevMaterial m = load_material(sc, material_id);
             V3 throughput = f4v(th), radiance = f4v(ra);
             const uint32_t tw = __float_as_uint(th.w);
             uint32_t channel = tw & 0xFFu;
             const uint32_t depth = tw >> 8;
             SimpleRng rng = {__float_as_uint(ra.w)};
-            const uint32_t vis = wb.vis[id];
             const bool terminal = depth >= fr.max_bounce;
             // direct light: the reference's loop order (lighting.rs:33-43), occluded lights skipped
             V3 lighting = v3(0.0f, 0.0f, 0.0f);
@@ -416,7 +474,7 @@ __global__ __launch_bounds__(256) void k_wf_finish(DevScene sc, DevFrame fr, rt:
             for (uint32_t li = 0; li < sc.n_lights; li++) {
                 V3 sdir;
                 float sdist;
-                const V3 contrib = light_contribution(sc.lights[li], m, point, normal, sdir, sdist);
+                const V3 contrib = light_contribution(s_lights[li], m, point, normal, sdir, sdist);
                 const bool nonzero = contrib.x != 0.0f || contrib.y != 0.0f || contrib.z != 0.0f;
                 if (nonzero && shadows && !((vis >> li) & 1u)) continue;
                 lighting = lighting + contrib;
@@ -430,7 +488,7 @@ __global__ __launch_bounds__(256) void k_wf_finish(DevScene sc, DevFrame fr, rt:
                 wf_end_path(wb, id, radiance);
             } else {
                 radiance = radiance + (lighting * (1.0f - tf)) * throughput;
-                const V3 din = f4v(wb.ray_d[id]);
+                const V3 din = f4v(rdin);
                 const bool front = dot(normal, din) < 0.0f;
                 const V3 nf = front ? normal : -normal;
                 bool transmit = false;

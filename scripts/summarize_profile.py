@@ -32,6 +32,7 @@ summary = {"frames": frames, "kernels": {kname(r["Name"]): {"calls": int(r["Call
                                                              "avg_us": float(r["AverageNs"]) / 1e3} for r in rows}}
 summary["kernel_ms_per_frame"] = sum(v["total_ms_per_frame"] for v in summary["kernels"].values())
 pmc = {}
+by_kernel = collections.defaultdict(dict)
 for d in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq"):
     fs = glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv"))
     if not fs:
@@ -39,10 +40,20 @@ for d in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq"):
     agg = collections.defaultdict(float)
     for r in csv.DictReader(open(fs[0])):
         if match in r["Kernel_Name"] and "<true" not in r["Kernel_Name"]:
-            agg[r["Counter_Name"]] += float(r["Counter_Value"]) / nframes(r["Kernel_Name"])
+            v = float(r["Counter_Value"]) / nframes(r["Kernel_Name"])
+            agg[r["Counter_Name"]] += v
+            kn = kname(r["Kernel_Name"])
+            by_kernel[kn][r["Counter_Name"]] = by_kernel[kn].get(r["Counter_Name"], 0.0) + v
     for k, v in agg.items():
         pmc[k] = v
 summary["pmc_per_frame"] = pmc
+for kn, c in by_kernel.items(): # per-kernel HBM bytes (same unit / gfx950 correction as the totals below)
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        c["hbm_bytes"] = 2 * c["FETCH_SIZE"] * 1024 + c["WRITE_SIZE"] * 1024
+        ms = summary["kernels"].get(kn, {}).get("total_ms_per_frame")
+        if ms:
+            c["hbm_GBps"] = c["hbm_bytes"] / ms / 1e6
+summary["pmc_per_frame_by_kernel"] = by_kernel
 if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
     rd, wr = pmc["FETCH_SIZE"] * 1024, pmc["WRITE_SIZE"] * 1024
     summary["hbm_bytes_per_frame"] = {"read_x1": rd, "read_x2_gfx950_corrected": 2 * rd, "write": wr, "traffic": 2 * rd + wr}
