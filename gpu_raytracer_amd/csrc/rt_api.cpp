@@ -299,14 +299,12 @@ int ensure_wavefront(rt_ctx* ctx, DeviceState& d, uint32_t n_blocks, uint32_t ba
     HIPCHK(ctx, alloc((void**)&w.sample_rad, P * 16));
     HIPCHK(ctx, alloc((void**)&w.vis, P * 4));
     HIPCHK(ctx, alloc((void**)&w.pxy, P * 4));
-    // producers reserve queue space in windows (wavefront.hip): room for every real entry plus one partly used
-    // window per producing wave (4 waves per block, cu_count * 8 blocks) and the round-up of the last window
-    const size_t producer_waves = (size_t)rt::wf_shading_blocks() * 4;
-    const size_t pad_ext = (producer_waves + 1) * rt::wf_window(1), pad_shadow = (producer_waves + 1) * rt::wf_window(std::max(1u, n_lights));
-    HIPCHK(ctx, alloc((void**)&w.q_ext[0], (P + pad_ext) * 4));
-    HIPCHK(ctx, alloc((void**)&w.q_ext[1], (P + pad_ext) * 4));
+    // producers reserve queue space in windows (wavefront.hip): wf_queue_slots is the bound on real entries + padding
+    const uint32_t lights = std::max(1u, n_lights);
+    HIPCHK(ctx, alloc((void**)&w.q_ext[0], rt::wf_queue_slots(P, 1) * 4));
+    HIPCHK(ctx, alloc((void**)&w.q_ext[1], rt::wf_queue_slots(P, 1) * 4));
     HIPCHK(ctx, alloc((void**)&w.q_vtx, 16));
-    HIPCHK(ctx, alloc((void**)&w.q_shadow, (P * (size_t)std::max(1u, n_lights) + pad_shadow) * 4));
+    HIPCHK(ctx, alloc((void**)&w.q_shadow, rt::wf_queue_slots(P * (size_t)lights, lights) * 4));
     HIPCHK(ctx, alloc((void**)&w.counters, rt::WF_N_COUNTERS * sizeof(uint32_t)));
     HIPCHK(ctx, alloc((void**)&w.totals, 16 * sizeof(unsigned long long)));
     HIPCHK(ctx, alloc((void**)&w.accum, (size_t)std::max(1u, n_blocks) * 64 * 16));
@@ -333,10 +331,10 @@ uint32_t wavefront_batch(uint32_t n_blocks, uint32_t spp, uint32_t n_lights, siz
     uint64_t target_paths = 64ull << 20;
     if (const char* e = std::getenv("RT_WF_TARGET_PATHS")) target_paths = std::max<uint64_t>(1, std::strtoull(e, nullptr, 10));
     const uint64_t lights = std::max(1u, n_lights);
-    const uint64_t bytes_per_path = 8 * 16 + 4 + 4 + 2 * 4 + 4 * lights; // path state, vis, pxy, two extension queues, shadow queue
+    const uint64_t bytes_per_path = 8 * 16 + 4 + 4 + 2 * 10 + 10 * lights; // path state, vis, pxy, two extension queues, shadow queue (2.5 slots per entry)
     target_paths = std::min<uint64_t>(target_paths, free_bytes / 2 / bytes_per_path);
     target_paths = std::min<uint64_t>(target_paths, (uint64_t)RT_WF_ID_MASK + 1);
-    target_paths = std::min<uint64_t>(target_paths, (1ull << 31) / lights);
+    target_paths = std::min<uint64_t>(target_paths, (1ull << 30) / lights); // queue positions are 32-bit: 2.5 x paths x lights slots
     const uint64_t per_sample = std::max<uint64_t>(1, (uint64_t)n_blocks * 64u);
     const uint32_t max_batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(spp, target_paths / per_sample));
     const uint32_t n_batches = (spp + max_batch - 1) / max_batch;

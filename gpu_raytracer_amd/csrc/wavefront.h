@@ -23,7 +23,10 @@ enum WfCounter : uint32_t {
     WF_SHADOW_COUNT = 3, // shadow segments of this iteration
     WF_EXT_CURSOR = 4,   // persistent-kernel fetch cursors
     WF_SHADOW_CURSOR = 5,
-    WF_N_COUNTERS = 8
+    WF_EXT_WINDOW = 6,      // reservation window (a power of two) the current extension queue was written with
+    WF_SHADOW_WINDOW = 7,   // ... the shadow queue
+    WF_EXT_WINDOW_NEXT = 8, // ... the next extension queue
+    WF_N_COUNTERS = 12
 };
 
 struct WfBuffers {
@@ -57,7 +60,7 @@ struct WfBuffers {
 #define RT_WF_ID_MASK 0x07FFFFFFu
 
 uint32_t wf_shading_blocks(); // grid size (256-thread blocks) of the generate / shade / finish kernels
-uint32_t wf_window(uint32_t n_lights); // queue slots a producing wave reserves per atomic (shadow queue: >= 64 * n_lights)
+size_t wf_queue_slots(size_t max_entries, uint32_t per_lane); // allocation bound of a queue holding up to max_entries real entries, written with up to per_lane entries per lane and iteration
 uint32_t wf_persistent_waves(); // grid size (in 64-lane blocks) of the persistent traversal kernels on the current device
 hipError_t wf_generate(const DevScene& sc, const DevFrame& fr, const WfBuffers& wb, uint32_t first_sample, uint32_t n_samples, hipStream_t s);
 hipError_t wf_bounce(const DevScene& sc, const DevFrame& fr, const WfBuffers& wb, uint32_t iteration, bool counters, hipStream_t s);

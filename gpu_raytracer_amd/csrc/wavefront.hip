@@ -27,11 +27,18 @@ using namespace rtdev;
 #ifndef RT_WF_CHUNK
 #define RT_WF_CHUNK 256 /* queue entries a wave claims per atomic */
 #endif
+#ifndef RT_WF_CHUNK_MAX
+#define RT_WF_CHUNK_MAX 256 /* ... at most.  Larger (guided) chunks were slower: 512 same, 1024 -1.5 %, 2048 -5 %, 8192 -12 %: small chunks keep the
+                               waves on neighbouring parts of the queue, i.e. on neighbouring rays, and the cursor atomics are not the bound */
+#endif
 #ifndef RT_WF_WINDOW
 #define RT_WF_WINDOW 512 /* queue slots a producing wave reserves per atomic */
 #endif
 #ifndef RT_WF_LEAF_THRESHOLD
 #define RT_WF_LEAF_THRESHOLD 24 /* lanes holding a postponed leaf before the triangle tests run */
+#endif
+#ifndef RT_WF_BLOCK_MAJOR
+#define RT_WF_BLOCK_MAJOR 1 /* path slots: all samples of a pixel block adjacent (1) or all blocks of a sample adjacent (0) */
 #endif
 #ifndef RT_WF_SHADE_WAVES
 #define RT_WF_SHADE_WAVES 4 /* waves per SIMD the shading stages are register-allocated for */
@@ -52,10 +59,29 @@ namespace {
 __device__ __forceinline__ V3 f4v(float4 a) { return v3(a.x, a.y, a.z); }
 
 // Queue output through wave-private windows.  A single counter sustains ~90 M atomics/s (MI355X_MICROARCH.md,
-// "dequeue"); one atomic per wave-iteration (1.7 M per stage and bounce at 8 spp) made the shading stages
-// atomic-bound.  Here a wave reserves RT_WF_WINDOW (or more) slots per atomic and hands them out itself; what
-// it does not use is filled with WF_SENTINEL entries, which the consumers skip.  Real entries are tallied
-// separately (totals) because queue lengths now include the padding.
+// "dequeue"): one atomic per wave-iteration made the shading stages atomic-bound, and so did fixed 512-slot
+// windows once batches grew (160 M shadow entries = 312 k atomics = 3.5 ms of a 5 ms launch).  A producing wave
+// therefore reserves a window sized from the launch: a quarter of what it can emit in total, as a power of two
+// between the minimum and RT_WF_WINDOW_MAX, i.e. about four atomics per wave and launch.  What a wave does not
+// use is filled with WF_SENTINEL entries.  All windows of a launch have the same size W and start at multiples of
+// W, and a window's sentinels are always its tail, so a consumer that meets a sentinel skips to the next multiple
+// of W (k_wf_trace); W travels through the counters.  Real entries are tallied separately (totals) because
+// queue lengths include the padding.
+#ifndef RT_WF_WINDOW_MAX
+#define RT_WF_WINDOW_MAX 16384u
+#endif
+__host__ __device__ inline uint32_t wf_min_window(uint32_t per_lane) { // >= 2 x the largest request of one wave iteration
+    uint32_t w = RT_WF_WINDOW;
+    while (w < 128u * per_lane) w <<= 1;
+    return w;
+}
+// iters: iterations a producing wave will run at most; per_lane: entries a lane can emit per iteration
+__device__ __forceinline__ uint32_t pick_window(uint32_t iters, uint32_t per_lane) {
+    const uint32_t most = iters * WAVE * per_lane;
+    uint32_t w = wf_min_window(per_lane);
+    while (w < most / 4u && w < RT_WF_WINDOW_MAX) w <<= 1;
+    return w;
+}
 struct OutWindow {
     uint32_t next, end; // wave-uniform
 };
@@ -70,11 +96,10 @@ __device__ __forceinline__ uint32_t window_reserve(uint32_t* __restrict__ queue,
     if (w.next + total > w.end) {
         window_close(queue, w);
         uint32_t base = 0;
-        const uint32_t want = max(window, total);
-        if ((threadIdx.x & 63u) == 0) base = atomicAdd(counter, want);
+        if ((threadIdx.x & 63u) == 0) base = atomicAdd(counter, window); // total <= window / 2 by construction (wf_min_window)
         base = __shfl(base, 0, WAVE);
         w.next = base;
-        w.end = base + want;
+        w.end = base + window;
     }
     const uint32_t at = w.next + incl - mine;
     w.next += total;
@@ -98,8 +123,17 @@ __global__ __launch_bounds__(256) void k_wf_generate(DevFrame fr, rt::WfBuffers 
     const uint32_t n_waves = gridDim.x * 4u, wave = blockIdx.x * 4u + (threadIdx.x >> 6);
     OutWindow win = {0u, 0u};
     uint32_t real = 0;
-    for (uint32_t sb = wave; sb < n_slots_blocks; sb += n_waves) { // sb = k * n_blocks + b
-        const uint32_t k = sb / wb.n_blocks, b = sb - k * wb.n_blocks;
+    const uint32_t window = pick_window((n_slots_blocks + n_waves - 1u) / n_waves, 1u);
+    if (blockIdx.x == 0 && threadIdx.x == 0) wb.counters[rt::WF_EXT_WINDOW] = window;
+    // path slot p = (b * n_samples + k) * 64 + lane: all samples of an 8x8 pixel block are neighbours in the queue, so
+    // the segments in flight at any moment (queue order survives compaction) come from a small part of the image
+    const uint32_t n_samples = n_slots_blocks / max(1u, wb.n_blocks);
+    for (uint32_t sb = wave; sb < n_slots_blocks; sb += n_waves) {
+#if RT_WF_BLOCK_MAJOR
+        const uint32_t b = sb / n_samples, k = sb - b * n_samples; // sb = b * n_samples + k
+#else
+        const uint32_t k = sb / wb.n_blocks, b = sb - k * wb.n_blocks; // sb = k * n_blocks + b
+#endif
         const PixelCoord px = block_pixel_at(fr, b, lane);
         const uint32_t p = sb * WAVE + lane;
         if (px.valid) {
@@ -123,7 +157,7 @@ __global__ __launch_bounds__(256) void k_wf_generate(DevFrame fr, rt::WfBuffers 
         const uint32_t mine = px.valid ? 1u : 0u;
         const uint32_t incl = wave_incl_scan(mine), total = __shfl(incl, WAVE - 1, WAVE);
         if (total) {
-            const uint32_t at = window_reserve(wb.q_ext[0], &wb.counters[rt::WF_EXT_COUNT], win, RT_WF_WINDOW, mine, incl, total);
+            const uint32_t at = window_reserve(wb.q_ext[0], &wb.counters[rt::WF_EXT_COUNT], win, window, mine, incl, total);
             if (mine) wb.q_ext[0][at] = p;
             real += mine;
         }
@@ -138,14 +172,16 @@ __global__ __launch_bounds__(256) void k_wf_generate(DevFrame fr, rt::WfBuffers 
 // ---------------------------------------------------------------------------------------------------------
 template <bool COUNT, bool ANY>
 __global__ __launch_bounds__(WAVE, RT_WF_MIN_WAVES) void k_wf_trace(DevScene sc, rt::WfBuffers wb, const uint32_t* __restrict__ queue, uint32_t count_slot,
-                                                   uint32_t cursor_slot) {
+                                                   uint32_t cursor_slot, uint32_t window_slot) {
     extern __shared__ uint32_t s_stack[];
     const uint32_t lane = threadIdx.x;
     uint32_t* __restrict__ stack = s_stack + lane;
     uint32_t* __restrict__ ovf = wb.stack_ovf + (size_t)blockIdx.x * wb.ovf_entries * WAVE + lane;
     const uint4* __restrict__ nodes = reinterpret_cast<const uint4*>(sc.nodes);
     const uint32_t count = wb.counters[count_slot];
+    const uint32_t window_mask = max(wb.counters[window_slot], 1u) - 1u; // the producers' window size is a power of two
     uint32_t* cursor = &wb.counters[cursor_slot];
+    uint32_t cursor_seen = 0; // the furthest queue position this wave knows to be handed out (wave-uniform)
     Counts cnt = {0u, 0u};
     int sp_max = 0;
     uint32_t sp_gt16 = 0, sp_gt24 = 0;
@@ -173,19 +209,29 @@ __global__ __launch_bounds__(WAVE, RT_WF_MIN_WAVES) void k_wf_trace(DevScene sc,
         const unsigned long long idle = __ballot(!active);
         if (!exhausted && (__popcll(idle) >= RT_WF_REFILL || idle == ~0ull)) {
             if (chunk_next >= chunk_end) {
+                // guided self-scheduling: claim 1/(2 x waves) of what is left, at least RT_WF_CHUNK entries.  Fixed
+                // 256-entry chunks cost one atomic per 256 entries on ONE address (650 k per large launch, ~7 ms
+                // of its 22 ms at ~90 M atomics/s); this needs a few dozen per wave and still ends balanced.
+                const uint32_t left = count > cursor_seen ? count - cursor_seen : 0u;
+                const uint32_t want = min(max(left / (2u * gridDim.x), (uint32_t)RT_WF_CHUNK), (uint32_t)RT_WF_CHUNK_MAX) & ~63u;
                 uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(cursor, (uint32_t)RT_WF_CHUNK);
+                if (lane == 0) base = atomicAdd(cursor, want);
                 base = __shfl(base, 0, WAVE);
+                cursor_seen = base + want;
                 chunk_next = base;
-                chunk_end = min(base + (uint32_t)RT_WF_CHUNK, count);
+                chunk_end = min(base + want, count);
                 if (base >= count) exhausted = true;
             }
             if (!exhausted) {
                 if (COUNT) d_refills++;
+                const uint32_t n_fetch = (uint32_t)__popcll(idle);
                 const uint32_t idx = chunk_next + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-                chunk_next += (uint32_t)__popcll(idle);
+                const uint32_t last = min(chunk_next + n_fetch, chunk_end) - 1u; // last position fetched now
+                chunk_next += n_fetch;
                 uint32_t e = WF_SENTINEL;
                 if (!active && idx < chunk_end) e = queue[idx];
+                // sentinels are the tail of a producer window: if the last entry fetched is one, so is the rest of its window
+                if (__ballot(!active && idx == last && e == WF_SENTINEL) != 0ull) chunk_next = max(chunk_next, (last + window_mask + 1u) & ~window_mask);
                 if (e != WF_SENTINEL) { // padding entries of the producers' windows carry no work
                     if (ANY) {
                         id = e & RT_WF_ID_MASK;
@@ -335,6 +381,8 @@ __global__ __launch_bounds__(256, RT_WF_SHADE_WAVES) void k_wf_shade(DevScene sc
     const uint32_t stride = gridDim.x * blockDim.x;
     OutWindow win = {0u, 0u};
     uint32_t n_shadow = 0;
+    const uint32_t window = pick_window((count + stride - 1u) / stride, max(1u, sc.n_lights));
+    if (blockIdx.x == 0 && threadIdx.x == 0) wb.counters[rt::WF_SHADOW_WINDOW] = window;
     // every wave runs the same number of iterations so the wave-aggregated appends see whole waves
     uint32_t id_next = blockIdx.x * blockDim.x + threadIdx.x < count ? queue[blockIdx.x * blockDim.x + threadIdx.x] : WF_SENTINEL;
     for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += stride) {
@@ -393,7 +441,7 @@ __global__ __launch_bounds__(256, RT_WF_SHADE_WAVES) void k_wf_shade(DevScene sc
             uint32_t total = 0;
             for (uint32_t li = 0; li < sc.n_lights; li++) total += (uint32_t)__popcll(__ballot((mask >> li) & 1u));
             if (total) {
-                uint32_t at = window_reserve(wb.q_shadow, &wb.counters[rt::WF_SHADOW_COUNT], win, max((uint32_t)RT_WF_WINDOW, sc.n_lights * WAVE), 0u, 0u, total);
+                uint32_t at = window_reserve(wb.q_shadow, &wb.counters[rt::WF_SHADOW_COUNT], win, window, 0u, 0u, total);
                 n_shadow += (uint32_t)__popc(mask);
                 const unsigned long long below = (1ull << (threadIdx.x & 63u)) - 1ull;
                 for (uint32_t li = 0; li < sc.n_lights; li++) {
@@ -407,7 +455,7 @@ __global__ __launch_bounds__(256, RT_WF_SHADE_WAVES) void k_wf_shade(DevScene sc
             const uint32_t mine = (uint32_t)__popc(mask);
             const uint32_t incl = wave_incl_scan(mine), total = __shfl(incl, WAVE - 1, WAVE);
             if (total) {
-                uint32_t at = window_reserve(wb.q_shadow, &wb.counters[rt::WF_SHADOW_COUNT], win, max((uint32_t)RT_WF_WINDOW, sc.n_lights * WAVE), mine, incl, total);
+                uint32_t at = window_reserve(wb.q_shadow, &wb.counters[rt::WF_SHADOW_COUNT], win, window, mine, incl, total);
                 n_shadow += mine;
                 while (mask) {
                     const uint32_t li = (uint32_t)__ffs((int)mask) - 1u;
@@ -435,6 +483,8 @@ __global__ __launch_bounds__(256, RT_WF_SHADE_WAVES) void k_wf_finish(DevScene s
     const uint32_t stride = gridDim.x * blockDim.x;
     OutWindow win = {0u, 0u};
     uint32_t n_cont = 0;
+    const uint32_t window = pick_window((count + stride - 1u) / stride, 1u);
+    if (blockIdx.x == 0 && threadIdx.x == 0) wb.counters[rt::WF_EXT_WINDOW_NEXT] = window;
     uint32_t id_next = blockIdx.x * blockDim.x + threadIdx.x < count ? queue[blockIdx.x * blockDim.x + threadIdx.x] : WF_SENTINEL;
     for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += stride) {
         bool cont = false;
@@ -552,7 +602,7 @@ __global__ __launch_bounds__(256, RT_WF_SHADE_WAVES) void k_wf_finish(DevScene s
         const uint32_t mine = cont ? 1u : 0u;
         const uint32_t incl = wave_incl_scan(mine), total = __shfl(incl, WAVE - 1, WAVE);
         if (total) {
-            const uint32_t at = window_reserve(next_queue, &wb.counters[rt::WF_EXT_NEXT], win, RT_WF_WINDOW, mine, incl, total);
+            const uint32_t at = window_reserve(next_queue, &wb.counters[rt::WF_EXT_NEXT], win, window, mine, incl, total);
             if (cont) next_queue[at] = id;
             n_cont += mine;
         }
@@ -567,6 +617,7 @@ __global__ void k_wf_advance(rt::WfBuffers wb, uint32_t iteration) {
     uint32_t* c = wb.counters;
     (void)iteration; // segment totals are tallied by the producing kernels (queue lengths include window padding)
     c[rt::WF_EXT_COUNT] = c[rt::WF_EXT_NEXT];
+    c[rt::WF_EXT_WINDOW] = c[rt::WF_EXT_WINDOW_NEXT];
     c[rt::WF_EXT_NEXT] = 0;
     c[rt::WF_VTX_COUNT] = 0;
     c[rt::WF_SHADOW_COUNT] = 0;
@@ -583,7 +634,7 @@ __global__ __launch_bounds__(WAVE) void k_wf_resolve(DevFrame fr, rt::WfBuffers 
     const uint32_t q = b * WAVE + lane;
     float4 acc = first_batch ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : wb.accum[q];
     V3 sum = f4v(acc);
-    for (uint32_t k = 0; k < n_samples; k++) sum = sum + f4v(wb.sample_rad[(size_t)(k * wb.n_blocks + b) * WAVE + lane]);
+    for (uint32_t k = 0; k < n_samples; k++) sum = sum + f4v(wb.sample_rad[(size_t)(RT_WF_BLOCK_MAJOR ? b * n_samples + k : k * wb.n_blocks + b) * WAVE + lane]);
     wb.accum[q] = make_float4(sum.x, sum.y, sum.z, 0.0f);
     if (!last_batch) return;
     const PixelCoord px = block_pixel_at(fr, b, lane);
@@ -613,7 +664,14 @@ int cu_count() {
 namespace rt {
 
 uint32_t wf_shading_blocks() { return (uint32_t)(cu_count() * 8); }
-uint32_t wf_window(uint32_t n_lights) { return std::max<uint32_t>(RT_WF_WINDOW, n_lights * WAVE); }
+// Slots a queue can take up: a wave's reservations hold at least half real entries each (a request is at most half
+// the minimum window), plus one window it may leave unused at the end: <= 2 x real + waves x W, and
+// W <= max(minimum, half of what the wave can emit), so summed over the producing waves
+// <= 2.5 x max_entries + waves x (minimum window + one iteration's worth).
+size_t wf_queue_slots(size_t max_entries, uint32_t per_lane) {
+    const size_t waves = (size_t)wf_shading_blocks() * 4;
+    return max_entries * 5 / 2 + (waves + 1) * ((size_t)wf_min_window(per_lane) + 64u * per_lane) + RT_WF_WINDOW_MAX;
+}
 uint32_t wf_persistent_waves() { return (uint32_t)(cu_count() * RT_WF_WAVES_PER_CU); }
 
 hipError_t wf_generate(const DevScene&, const DevFrame& fr, const WfBuffers& wb, uint32_t first_sample, uint32_t n_samples, hipStream_t s) {
@@ -631,15 +689,15 @@ hipError_t wf_bounce(const DevScene& sc, const DevFrame& fr, const WfBuffers& wb
     uint32_t* cur_q = wb.q_ext[iteration & 1u];
     uint32_t* next_q = wb.q_ext[(iteration + 1u) & 1u];
     if (counters)
-        hipLaunchKernelGGL((k_wf_trace<true, false>), pgrid, pblock, lds, s, sc, wb, (const uint32_t*)cur_q, (uint32_t)WF_EXT_COUNT, (uint32_t)WF_EXT_CURSOR);
+        hipLaunchKernelGGL((k_wf_trace<true, false>), pgrid, pblock, lds, s, sc, wb, (const uint32_t*)cur_q, (uint32_t)WF_EXT_COUNT, (uint32_t)WF_EXT_CURSOR, (uint32_t)WF_EXT_WINDOW);
     else
-        hipLaunchKernelGGL((k_wf_trace<false, false>), pgrid, pblock, lds, s, sc, wb, (const uint32_t*)cur_q, (uint32_t)WF_EXT_COUNT, (uint32_t)WF_EXT_CURSOR);
+        hipLaunchKernelGGL((k_wf_trace<false, false>), pgrid, pblock, lds, s, sc, wb, (const uint32_t*)cur_q, (uint32_t)WF_EXT_COUNT, (uint32_t)WF_EXT_CURSOR, (uint32_t)WF_EXT_WINDOW);
     hipLaunchKernelGGL(k_wf_shade, sgrid, sblock, 0, s, sc, fr, wb, (const uint32_t*)cur_q);
     if ((fr.flags & 2u) == 0) {
         if (counters)
-            hipLaunchKernelGGL((k_wf_trace<true, true>), pgrid, pblock, lds, s, sc, wb, (const uint32_t*)wb.q_shadow, (uint32_t)WF_SHADOW_COUNT, (uint32_t)WF_SHADOW_CURSOR);
+            hipLaunchKernelGGL((k_wf_trace<true, true>), pgrid, pblock, lds, s, sc, wb, (const uint32_t*)wb.q_shadow, (uint32_t)WF_SHADOW_COUNT, (uint32_t)WF_SHADOW_CURSOR, (uint32_t)WF_SHADOW_WINDOW);
         else
-            hipLaunchKernelGGL((k_wf_trace<false, true>), pgrid, pblock, lds, s, sc, wb, (const uint32_t*)wb.q_shadow, (uint32_t)WF_SHADOW_COUNT, (uint32_t)WF_SHADOW_CURSOR);
+            hipLaunchKernelGGL((k_wf_trace<false, true>), pgrid, pblock, lds, s, sc, wb, (const uint32_t*)wb.q_shadow, (uint32_t)WF_SHADOW_COUNT, (uint32_t)WF_SHADOW_CURSOR, (uint32_t)WF_SHADOW_WINDOW);
     }
     hipLaunchKernelGGL(k_wf_finish, sgrid, sblock, 0, s, sc, fr, wb, (const uint32_t*)cur_q, next_q);
     hipLaunchKernelGGL(k_wf_advance, dim3(1), dim3(1), 0, s, wb, iteration);
