@@ -10,7 +10,7 @@ with api.Context() as ctx:
     full = ctx.render(1920, 1080, sp.camera, mode=2, spp=spp, max_bounces=4)
     print(f"full frame: {full['kernel_ms']:.2f} ms, {full['rays']/1e6:.1f} M segments")
     for world in (2, 4, 8):
-        for ts in (128, 64, 32, 16):
+        for ts in (128, 64, 32):
             ms, rays = [], []
             for r in range(world):
                 st = ctx.render(1920, 1080, sp.camera, mode=2, spp=spp, max_bounces=4, tile_size=ts, tile_rank=r, tile_world=world)

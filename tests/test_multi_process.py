@@ -28,7 +28,7 @@ def test_bench_glue_gloo(world):
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout  # rank 0 prints ONE JSON line
     j = json.loads(lines[0])
-    assert j["n_ranks"] == world and j["tiles_total"] == j["tiles_expected"] == 135
+    assert j["n_ranks"] == world and j["tiles_total"] == j["tiles_expected"] == 60 * 34  # 1080p in the 32x32 tiles bench.py deals over several ranks
     assert j["max_dt"] >= 0.01 * world  # the MAX over ranks, not rank 0's own time
 
 
