@@ -97,3 +97,39 @@ def test_extended_full_size_properties(gpu_ctx):
     for kw in ({"kernel_sm": True}, {"kernel_v1": True}):
         gpu_ctx.render(w, h, scene.camera, mode=2, spp=4, max_bounces=4, **kw)
         np.testing.assert_array_equal(gpu_ctx.read_rgb32f().view(np.uint32), a.view(np.uint32))
+
+
+@pytest.mark.parametrize("n_lights", [9, 32, 40])
+def test_extended_many_lights(gpu_ctx, oracle_mod, n_lights):
+    """Shadow-queue windows grow with the light count (>= 128 slots per light), visibility is one bit per light in a
+    32-bit word, and more than 32 lights take the state-machine megakernel: all bit-exact against the CPU statement."""
+    scene = scenes.random_soup(600, seed=5, size=0.6, n_spheres=1, n_lights=n_lights)
+    ref = oracle_mod.render_extended(oracle_mod.PackedScene(scene, use_bvh=False), 64, 40, 3, 2, frame_seed=3)
+    rgb, st = _gpu_ext(gpu_ctx, scene, 64, 40, 3, 2, frame_seed=3)
+    seg = ref["segments"]
+    assert (st["primary_rays"], st["continuation_rays"], st["shadow_rays"]) == (seg["camera"], seg["continuation"], seg["shadow"])
+    np.testing.assert_array_equal(rgb.view(np.uint32), ref["rgb"].view(np.uint32))
+
+
+def test_extended_image_independent_of_batching_and_tiles(rt_api, monkeypatch):
+    """The wavefront pipeline's scheduling knobs - samples per batch, tile size, tile partition - only change WHEN a
+    path's next step runs: same bits for 1, 3 and all samples per batch, for 16/64/128-pixel tiles."""
+    scene = scenes.sponza_like()
+    w, h, spp, bounces = 480, 270, 7, 3
+    images = {}
+    for batch in ("1", "3", "0"):  # 0 = the library's own choice
+        monkeypatch.setenv("RT_WF_BATCH", batch)
+        with rt_api.Context() as ctx:  # a fresh context: an allocation is reused for the same frame shape
+            ctx.upload_scene(scene)
+            ctx.render(w, h, scene.camera, mode=2, spp=spp, max_bounces=bounces)
+            images["batch" + batch] = ctx.read_rgb32f()
+    monkeypatch.delenv("RT_WF_BATCH")
+    with rt_api.Context() as ctx:
+        ctx.upload_scene(scene)
+        for ts in (16, 64, 128):
+            ctx.render(w, h, scene.camera, mode=2, spp=spp, max_bounces=bounces, tile_size=ts)
+            images[f"tile{ts}"] = ctx.read_rgb32f()
+    ref = images["batch0"]
+    assert np.isfinite(ref).all()
+    for k, img in images.items():
+        np.testing.assert_array_equal(img.view(np.uint32), ref.view(np.uint32), err_msg=k)
