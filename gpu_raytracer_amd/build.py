@@ -40,6 +40,24 @@ def build(force=False, verbose=True, extra=(), out=None):
     return LIB
 
 
+EXAMPLE_SRC = os.path.join(HERE, "..", "examples", "rt_render.cpp")
+EXAMPLE_BIN = os.path.join(HERE, "..", "build", "rt_render")
+
+
+def build_examples(force=False, verbose=True):
+    """examples/rt_render.cpp: the native headless front end over the C ABI (host-only C++, links librt_hip.so)."""
+    deps = [EXAMPLE_SRC, LIB] + [os.path.join(CSRC, "host", f) for f in os.listdir(os.path.join(CSRC, "host"))]
+    if not force and os.path.exists(EXAMPLE_BIN) and all(os.path.getmtime(d) <= os.path.getmtime(EXAMPLE_BIN) for d in deps):
+        return EXAMPLE_BIN
+    os.makedirs(os.path.dirname(EXAMPLE_BIN), exist_ok=True)
+    cmd = [os.environ.get("CXX", "g++"), "-std=c++17", "-O2", "-Wall", EXAMPLE_SRC, "-I" + os.path.join(HERE, "..", "include"), "-I" + CSRC,
+           "-L" + HERE, "-lrt_hip", "-Wl,-rpath,$ORIGIN/../gpu_raytracer_amd", "-o", EXAMPLE_BIN]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return EXAMPLE_BIN
+
+
 if __name__ == "__main__":
     out = None
     args = sys.argv[1:]
@@ -48,3 +66,5 @@ if __name__ == "__main__":
         out = args[i + 1]
         del args[i:i + 2]
     build(force="--force" in args, extra=[a for a in args if a.startswith("-") and a != "--force"], out=out)
+    if out is None:
+        build_examples(force="--force" in args)

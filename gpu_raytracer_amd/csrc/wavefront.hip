@@ -46,6 +46,9 @@ using namespace rtdev;
 #ifndef RT_WF_LEAF_POLICY
 #define RT_WF_LEAF_POLICY 0 /* 0: triangle tests run when RT_WF_LEAF_THRESHOLD lanes hold a leaf; 1: when that many lanes are blocked on theirs */
 #endif
+#ifndef RT_WF_LEAF_THRESHOLD_ANY
+#define RT_WF_LEAF_THRESHOLD_ANY RT_WF_LEAF_THRESHOLD /* ... for shadow segments (a postponed leaf may hold the occluder that ends the walk) */
+#endif
 #ifndef RT_WF_WAVES_PER_CU
 #define RT_WF_WAVES_PER_CU 24
 #endif
@@ -312,7 +315,7 @@ __global__ __launch_bounds__(WAVE, RT_WF_MIN_WAVES) void k_wf_trace(DevScene sc,
 #else
             const unsigned long long m_gate = m_leaf;
 #endif
-            if (m_node != 0ull && __popcll(m_gate) < RT_WF_LEAF_THRESHOLD) {
+            if (m_node != 0ull && __popcll(m_gate) < (ANY ? RT_WF_LEAF_THRESHOLD_ANY : RT_WF_LEAF_THRESHOLD)) {
                 if (COUNT) d_node_steps++;
                 if (can_node) {
                     if (!visit_node4<COUNT, RT_WF_LDS_STACK>(nodes, fray, hit.t, stack, sp, cur, cnt, ovf)) cur = WF_REF_NONE;

@@ -152,3 +152,51 @@ def test_gltf_scene_through_the_whole_drop_in_path_on_gpu(gpu_ctx, oracle_mod, t
     assert t["calls"] == 1 and t["tiles"] == 15 and t["total_ms"] > 0 and t["p50_ms"] <= t["p99_ms"] and t["tiles_per_s"] > 0
     host.write_image(tmp_path / "cornell.png", comb)
     assert (tmp_path / "cornell.png").stat().st_size > w * h * 4
+
+
+def _rt_render_binary():
+    from gpu_raytracer_amd import build as rt_build
+    return rt_build.build_examples(verbose=False)
+
+
+def test_native_front_end_builds_and_fails_loudly_without_a_device():
+    """examples/rt_render.cpp (C++ over the C ABI and the host mirror) builds with g++ alone; on a box without a HIP
+    device it must stop with the library's error, not render on the CPU."""
+    import subprocess
+    exe = _rt_render_binary()
+    out = subprocess.run([exe, "--help"], capture_output=True, text=True)
+    assert out.returncode == 0 and "--gltf" in out.stdout
+    out = subprocess.run([exe, "--bogus"], capture_output=True, text=True)
+    assert out.returncode == 2
+    import torch
+    if not torch.cuda.is_available():
+        out = subprocess.run([exe, "--size", "32x32", "--out", os.devnull], capture_output=True, text=True)
+        assert out.returncode == 4 and "no CPU fallback" in out.stderr
+
+
+@pytest.mark.gpu
+def test_native_front_end_renders_the_gltf_fixture_like_the_oracle(oracle_mod, tmp_path):
+    """The same drop-in path as above, driven by the native C++ front end: its PPM equals the oracle's combined frame;
+    and the extended mode through the same binary equals the Python-driven render."""
+    import subprocess
+    exe = _rt_render_binary()
+    w, h = 300, 200
+    ppm = tmp_path / "cornell.ppm"
+    out = subprocess.run([exe, "--gltf", os.path.join(GOLD, "cornell12.gltf"), "--size", f"{w}x{h}", "--out", str(ppm)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert "progressive rendering complete: 6 tiles (3x2) in 1 calls" in out.stdout
+    raw = ppm.read_bytes()
+    header = f"P6\n{w} {h}\n255\n".encode()
+    assert raw.startswith(header)
+    img = np.frombuffer(raw[len(header):], np.uint8).reshape(h, w, 3)
+    scene = host.load_gltf(os.path.join(GOLD, "cornell12.gltf"))
+    ref = oracle_mod.render_frame(oracle_mod.PackedScene(scene, use_bvh=False), w, h)
+    np.testing.assert_array_equal(img, ref["combined"][..., :3])
+    ppm2 = tmp_path / "ext.ppm"
+    out = subprocess.run([exe, "--size", "160x120", "--spp", "4", "--bounces", "2", "--out", str(ppm2)], capture_output=True, text=True)
+    assert out.returncode == 0 and "extended mode: 4 spp, 2 bounces" in out.stdout, out.stderr
+    ext = oracle_mod.render_extended(oracle_mod.PackedScene(scenes.default_scene(), use_bvh=False), 160, 120, 4, 2)
+    raw2 = ppm2.read_bytes()
+    img2 = np.frombuffer(raw2[len(b"P6\n160 120\n255\n"):], np.uint8).reshape(120, 160, 3)
+    exp = np.clip(np.floor(np.clip(ext["rgb"], 0, 1) * 255.0 + 0.5), 0, 255).astype(np.uint8)
+    np.testing.assert_array_equal(img2, exp)
