@@ -303,7 +303,6 @@ int ensure_wavefront(rt_ctx* ctx, DeviceState& d, uint32_t n_blocks, uint32_t ba
     const uint32_t lights = std::max(1u, n_lights);
     HIPCHK(ctx, alloc((void**)&w.q_ext[0], rt::wf_queue_slots(P, 1) * 4));
     HIPCHK(ctx, alloc((void**)&w.q_ext[1], rt::wf_queue_slots(P, 1) * 4));
-    HIPCHK(ctx, alloc((void**)&w.q_vtx, 16));
     HIPCHK(ctx, alloc((void**)&w.q_shadow, rt::wf_queue_slots(P * (size_t)lights, lights) * 4));
     HIPCHK(ctx, alloc((void**)&w.counters, rt::WF_N_COUNTERS * sizeof(uint32_t)));
     HIPCHK(ctx, alloc((void**)&w.totals, 16 * sizeof(unsigned long long)));

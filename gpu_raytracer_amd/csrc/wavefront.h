@@ -19,7 +19,7 @@ namespace rt {
 enum WfCounter : uint32_t {
     WF_EXT_COUNT = 0,    // entries in the current extension queue
     WF_EXT_NEXT = 1,     // entries appended to the next extension queue
-    WF_VTX_COUNT = 2,    // vertices awaiting wf_finish
+    WF_UNUSED_2 = 2,
     WF_SHADOW_COUNT = 3, // shadow segments of this iteration
     WF_EXT_CURSOR = 4,   // persistent-kernel fetch cursors
     WF_SHADOW_CURSOR = 5,
@@ -43,7 +43,6 @@ struct WfBuffers {
     uint32_t* pxy;       // x | y << 16, 0xFFFFFFFF = no pixel (tile edge)
     // queues
     uint32_t* q_ext[2];  // path ids to extend (double buffered)
-    uint32_t* q_vtx;     // path ids with a vertex awaiting its shadow results
     uint32_t* q_shadow;  // path id | light << 27
     uint32_t* counters;  // WfCounter
     unsigned long long* totals; // [0] camera [1] continuation [2] shadow segments, [3] node visits, [4] triangle tests

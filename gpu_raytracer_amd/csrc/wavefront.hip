@@ -652,7 +652,6 @@ __global__ void k_wf_advance(rt::WfBuffers wb, uint32_t iteration) {
     c[rt::WF_EXT_COUNT] = c[rt::WF_EXT_NEXT];
     c[rt::WF_EXT_WINDOW] = c[rt::WF_EXT_WINDOW_NEXT];
     c[rt::WF_EXT_NEXT] = 0;
-    c[rt::WF_VTX_COUNT] = 0;
     c[rt::WF_SHADOW_COUNT] = 0;
     c[rt::WF_EXT_CURSOR] = 0;
     c[rt::WF_SHADOW_CURSOR] = 0;
