@@ -46,9 +46,6 @@ using namespace rtdev;
 #ifndef RT_WF_LEAF_POLICY
 #define RT_WF_LEAF_POLICY 0 /* 0: triangle tests run when RT_WF_LEAF_THRESHOLD lanes hold a leaf; 1: when that many lanes are blocked on theirs */
 #endif
-#ifndef RT_WF_LEAF_THRESHOLD_ANY
-#define RT_WF_LEAF_THRESHOLD_ANY RT_WF_LEAF_THRESHOLD /* ... for shadow segments (a postponed leaf may hold the occluder that ends the walk) */
-#endif
 #ifndef RT_WF_WAVES_PER_CU
 #define RT_WF_WAVES_PER_CU 24
 #endif
@@ -205,80 +202,51 @@ __global__ __launch_bounds__(WAVE, RT_WF_MIN_WAVES) void k_wf_trace(DevScene sc,
     uint32_t cur = WF_REF_NONE, pleaf = WF_REF_NONE;
     int sp = 0;
 
-    // ---- staging buffer: segments are SET UP 64 at a time at full width (queue fetch, vertex / ray loads, the
-    // normalisation of a shadow direction with its IEEE square root and divide) and parked in LDS, 8 words per segment,
-    // field-major; idle lanes then take prepared segments from it.  Setting rays up inside the refill itself ran
-    // ~330 instructions at ~17 of 64 lanes once per 17 segments: 18 % of the stage's instructions.
-    uint32_t* __restrict__ stage = s_stack + RT_WF_LDS_STACK * WAVE;
-    uint32_t staged = 0, stage_next = 0; // wave-uniform: segments in the buffer, next one to hand out
-    const unsigned long long below = (1ull << lane) - 1ull;
-
     for (;;) {
+        // ---- refill: idle lanes take the next queue entries.  The wave owns a private chunk [chunk_next, chunk_end)
+        // of the queue and only touches the global cursor when it runs dry: a single counter sustains ~90 M
+        // atomics/s, far less than thousands of waves refilling 16 lanes at a time would ask of it.
         const unsigned long long idle = __ballot(!active);
-        if ((!exhausted || stage_next < staged) && (__popcll(idle) >= RT_WF_REFILL || idle == ~0ull)) {
-            if (stage_next >= staged && !exhausted) {
-                // the wave owns a private chunk [chunk_next, chunk_end) of the queue and only touches the global cursor
-                // when it runs dry: a single counter sustains ~90 M atomics/s
-                if (chunk_next >= chunk_end) {
-                    const uint32_t left = count > cursor_seen ? count - cursor_seen : 0u;
-                    const uint32_t want = min(max(left / (2u * gridDim.x), (uint32_t)RT_WF_CHUNK), (uint32_t)RT_WF_CHUNK_MAX) & ~63u;
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(cursor, want);
-                    base = __shfl(base, 0, WAVE);
-                    cursor_seen = base + want;
-                    chunk_next = base;
-                    chunk_end = min(base + want, count);
-                    if (base >= count) exhausted = true;
-                }
-                if (!exhausted) {
-                    if (COUNT) d_refills++;
-                    const uint32_t idx = chunk_next + lane;
-                    const uint32_t last = min(chunk_next + (uint32_t)WAVE, chunk_end) - 1u; // last position fetched now
-                    chunk_next += WAVE;
-                    uint32_t e = WF_SENTINEL;
-                    if (idx < chunk_end) e = queue[idx];
-                    // sentinels are the tail of a producer window: if the last entry fetched is one, so is the rest of its window
-                    if (__ballot(idx == last && e == WF_SENTINEL) != 0ull) chunk_next = max(chunk_next, (last + window_mask + 1u) & ~window_mask);
-                    const bool valid = e != WF_SENTINEL; // padding entries of the producers' windows carry no work
-                    V3 so = v3(0.0f, 0.0f, 0.0f), sd = so;
-                    float st = RT_F32_MAX;
-                    if (valid) {
-                        if (ANY) {
-                            const uint32_t sid = e & RT_WF_ID_MASK;
-                            const V3 point = f4v(wb.vtx_p[sid]), normal = f4v(wb.vtx_n[sid]);
-                            shadow_segment(sc.lights[e >> 27], point, sd, st);
-                            so = point + normal * EXT_EPS;
-                        } else {
-                            so = f4v(wb.ray_o[e]);
-                            sd = f4v(wb.ray_d[e]);
-                        }
-                    }
-                    const unsigned long long vm = __ballot(valid);
-                    if (valid) {
-                        uint32_t* __restrict__ slot = stage + (uint32_t)__popcll(vm & below);
-                        slot[0 * WAVE] = __float_as_uint(so.x);
-                        slot[1 * WAVE] = __float_as_uint(so.y);
-                        slot[2 * WAVE] = __float_as_uint(so.z);
-                        slot[3 * WAVE] = __float_as_uint(sd.x);
-                        slot[4 * WAVE] = __float_as_uint(sd.y);
-                        slot[5 * WAVE] = __float_as_uint(sd.z);
-                        slot[6 * WAVE] = __float_as_uint(st);
-                        slot[7 * WAVE] = e;
-                    }
-                    staged = (uint32_t)__popcll(vm);
-                    stage_next = 0;
-                }
+        if (!exhausted && (__popcll(idle) >= RT_WF_REFILL || idle == ~0ull)) {
+            if (chunk_next >= chunk_end) {
+                // guided self-scheduling: claim 1/(2 x waves) of what is left, at least RT_WF_CHUNK entries.  Fixed
+                // 256-entry chunks cost one atomic per 256 entries on ONE address (650 k per large launch, ~7 ms
+                // of its 22 ms at ~90 M atomics/s); this needs a few dozen per wave and still ends balanced.
+                const uint32_t left = count > cursor_seen ? count - cursor_seen : 0u;
+                const uint32_t want = min(max(left / (2u * gridDim.x), (uint32_t)RT_WF_CHUNK), (uint32_t)RT_WF_CHUNK_MAX) & ~63u;
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(cursor, want);
+                base = __shfl(base, 0, WAVE);
+                cursor_seen = base + want;
+                chunk_next = base;
+                chunk_end = min(base + want, count);
+                if (base >= count) exhausted = true;
             }
-            if (stage_next < staged) { // hand prepared segments to the idle lanes
-                const uint32_t at = stage_next + (uint32_t)__popcll(idle & below);
-                if (!active && at < staged) {
-                    const uint32_t* __restrict__ slot = stage + at;
-                    o = v3(__uint_as_float(slot[0 * WAVE]), __uint_as_float(slot[1 * WAVE]), __uint_as_float(slot[2 * WAVE]));
-                    d = v3(__uint_as_float(slot[3 * WAVE]), __uint_as_float(slot[4 * WAVE]), __uint_as_float(slot[5 * WAVE]));
-                    hit.t = __uint_as_float(slot[6 * WAVE]);
-                    const uint32_t e = slot[7 * WAVE];
-                    id = ANY ? (e & RT_WF_ID_MASK) : e;
-                    li = ANY ? (e >> 27) : 0u;
+            if (!exhausted) {
+                if (COUNT) d_refills++;
+                const uint32_t n_fetch = (uint32_t)__popcll(idle);
+                const uint32_t idx = chunk_next + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                const uint32_t last = min(chunk_next + n_fetch, chunk_end) - 1u; // last position fetched now
+                chunk_next += n_fetch;
+                uint32_t e = WF_SENTINEL;
+                if (!active && idx < chunk_end) e = queue[idx];
+                // sentinels are the tail of a producer window: if the last entry fetched is one, so is the rest of its window
+                if (__ballot(!active && idx == last && e == WF_SENTINEL) != 0ull) chunk_next = max(chunk_next, (last + window_mask + 1u) & ~window_mask);
+                if (e != WF_SENTINEL) { // padding entries of the producers' windows carry no work
+                    if (ANY) {
+                        id = e & RT_WF_ID_MASK;
+                        li = e >> 27;
+                        const V3 point = f4v(wb.vtx_p[id]), normal = f4v(wb.vtx_n[id]);
+                        float dist;
+                        shadow_segment(sc.lights[li], point, d, dist);
+                        o = point + normal * EXT_EPS;
+                        hit.t = dist;
+                    } else {
+                        id = e;
+                        o = f4v(wb.ray_o[id]);
+                        d = f4v(wb.ray_d[id]);
+                        hit.t = RT_F32_MAX;
+                    }
                     hit.prim = RT_PRIM_MISS;
                     hit.slot = 0;
                     fray = make_filter_ray(o, d);
@@ -289,11 +257,10 @@ __global__ __launch_bounds__(WAVE, RT_WF_MIN_WAVES) void k_wf_trace(DevScene sc,
                     active = true;
                     if (ANY && hit.prim != RT_PRIM_MISS) cur = WF_REF_NONE; // occluded by a sphere already
                 }
-                stage_next = min(staged, stage_next + (uint32_t)__popcll(idle));
             }
         }
         if (__ballot(active) == 0ull) {
-            if (exhausted && stage_next >= staged) break;
+            if (exhausted) break;
             continue;
         }
         // ---- traversal steps until enough lanes have finished ----
@@ -315,7 +282,7 @@ __global__ __launch_bounds__(WAVE, RT_WF_MIN_WAVES) void k_wf_trace(DevScene sc,
 #else
             const unsigned long long m_gate = m_leaf;
 #endif
-            if (m_node != 0ull && __popcll(m_gate) < (ANY ? RT_WF_LEAF_THRESHOLD_ANY : RT_WF_LEAF_THRESHOLD)) {
+            if (m_node != 0ull && __popcll(m_gate) < RT_WF_LEAF_THRESHOLD) {
                 if (COUNT) d_node_steps++;
                 if (can_node) {
                     if (!visit_node4<COUNT, RT_WF_LDS_STACK>(nodes, fray, hit.t, stack, sp, cur, cnt, ovf)) cur = WF_REF_NONE;
@@ -351,7 +318,7 @@ __global__ __launch_bounds__(WAVE, RT_WF_MIN_WAVES) void k_wf_trace(DevScene sc,
             }
             const unsigned long long still = __ballot(active);
             if (still == 0ull) break;
-            if ((!exhausted || stage_next < staged) && __popcll(~still) >= RT_WF_REFILL) break;
+            if (!exhausted && __popcll(~still) >= RT_WF_REFILL) break;
         }
     }
     if (COUNT) {
@@ -715,7 +682,7 @@ hipError_t wf_generate(const DevScene&, const DevFrame& fr, const WfBuffers& wb,
 }
 
 hipError_t wf_bounce(const DevScene& sc, const DevFrame& fr, const WfBuffers& wb, uint32_t iteration, bool counters, hipStream_t s) {
-    const size_t lds = (size_t)(RT_WF_LDS_STACK + 8) * WAVE * sizeof(uint32_t); // traversal stack + staging buffer (8 words per segment)
+    const size_t lds = (size_t)RT_WF_LDS_STACK * WAVE * sizeof(uint32_t);
     const dim3 pgrid(wf_persistent_waves()), pblock(WAVE);
     const dim3 sgrid(wf_shading_blocks()), sblock(256);
     uint32_t* cur_q = wb.q_ext[iteration & 1u];
