@@ -130,11 +130,34 @@ def cpu_baseline(scene, camera, sample, mode_name, spp, bounces):
         rays = r["counters"]["rays"]
         what = "1 spp primary rays"
     dt = time.perf_counter() - t0
-    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"{scene.name} {w}x{h} {what}, same camera, reference-format BVH ({len(packed.nodes)} nodes, no t-culling), "
-                      f"{rays} segments in {dt:.2f} s",
-            "nodes_per_ray": r["counters"]["node_visits"] / max(r["counters"]["rays"], 1),
-            "tris_per_ray": r["counters"]["tri_tests"] / max(r["counters"]["rays"], 1)}
+    out = {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+           "sample": f"{scene.name} {w}x{h} {what}, same camera, reference-format BVH ({len(packed.nodes)} nodes, no t-culling), "
+                     f"{rays} segments in {dt:.2f} s",
+           "nodes_per_ray": r["counters"]["node_visits"] / max(r["counters"]["rays"], 1),
+           "tris_per_ray": r["counters"]["tri_tests"] / max(r["counters"]["rays"], 1)}
+    # second flavour (SURVEY 8d ii): what the same cores do with a decent traversal - one triangle per leaf, children
+    # slab-tested against the closest hit, near child first, any-hit shadow segments.  Not the reference's algorithm
+    # (tests/test_oracle_extended.py shows it renders the same frames); a larger sample because it is ~100x faster.
+    try:
+        fw, fh = w * 4, h * 4
+        fast = oracle.PackedScene(scene, bvh=oracle.build_bvh(scene.triangles, scene.vertices, per_triangle=True))
+        oracle.set_fast_traversal(True)
+        t0 = time.perf_counter()
+        if mode_name == "extended":
+            r2 = oracle.render_extended(fast, fw, fh, sspp, bounces, camera=camera, threads=cores)
+            rays2 = sum(r2["segments"][k] for k in ("camera", "continuation", "shadow"))
+        else:
+            r2 = oracle.render_frame(fast, fw, fh, camera=camera, mode=1, threads=cores, want_rgba8=False, tile_size=32)
+            rays2 = r2["counters"]["rays"]
+        dt2 = time.perf_counter() - t0
+        out["culled_traversal"] = {"value": rays2 / dt2 / 1e6, "unit": "Mrays/s", "cores": cores,
+                                   "sample": f"{fw}x{fh}, {len(fast.nodes)}-node one-triangle-per-leaf BVH, ordered + distance-culled traversal, "
+                                             f"{rays2} segments in {dt2:.2f} s",
+                                   "nodes_per_ray": r2["counters"]["node_visits"] / max(r2["counters"]["rays"], 1),
+                                   "tris_per_ray": r2["counters"]["tri_tests"] / max(r2["counters"]["rays"], 1)}
+    finally:
+        oracle.set_fast_traversal(False)
+    return out
 
 
 def load_traffic(workload):

@@ -61,20 +61,27 @@ def _ptr(a):
     return C.c_void_p(a.ctypes.data) if a is not None and a.size else C.c_void_p(0)
 
 
-def build_bvh(triangles, vertices):
-    """BvhBuilder::build restatement -> (nodes, triangle_indices)."""
+def set_fast_traversal(on):
+    """Baseline flavour (ii): ordered, distance-culled traversal instead of the reference's (same image)."""
+    lib().oracle_set_fast_traversal(C.c_int(1 if on else 0))
+
+
+def build_bvh(triangles, vertices, per_triangle=False):
+    """BvhBuilder::build restatement -> (nodes, triangle_indices).  per_triangle: one triangle per leaf at every size
+    (baseline flavour ii; the reference chunks above 100,000 triangles)."""
     l = lib()
+    fn = l.oracle_build_bvh_per_triangle if per_triangle else l.oracle_build_bvh
     tris = np.ascontiguousarray(triangles)
     verts = np.ascontiguousarray(vertices)
     nn, ni = C.c_uint32(0), C.c_uint32(0)
-    rc = l.oracle_build_bvh(_ptr(tris), C.c_uint32(len(tris)), _ptr(verts), C.c_uint32(len(verts)),
-                            C.c_void_p(0), C.byref(nn), C.c_void_p(0), C.byref(ni))
+    rc = fn(_ptr(tris), C.c_uint32(len(tris)), _ptr(verts), C.c_uint32(len(verts)),
+            C.c_void_p(0), C.byref(nn), C.c_void_p(0), C.byref(ni))
     if rc != 0:
         raise ValueError(f"oracle_build_bvh failed: {rc}")
     nodes = np.zeros(nn.value, dtype=T.BVH_NODE)
     idx = np.zeros(ni.value, dtype=np.uint32)
-    rc = l.oracle_build_bvh(_ptr(tris), C.c_uint32(len(tris)), _ptr(verts), C.c_uint32(len(verts)),
-                            _ptr(nodes), C.byref(nn), _ptr(idx), C.byref(ni))
+    rc = fn(_ptr(tris), C.c_uint32(len(tris)), _ptr(verts), C.c_uint32(len(verts)),
+            _ptr(nodes), C.byref(nn), _ptr(idx), C.byref(ni))
     if rc != 0:
         raise ValueError(f"oracle_build_bvh failed: {rc}")
     return nodes, idx

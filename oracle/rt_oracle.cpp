@@ -299,6 +299,7 @@ struct Kernel {
     const rt_push_constants* pc;
     SceneAccessor sa;
     Counters* c;
+    bool fast = false; // baseline flavour (ii), see traverse_fast
 
     // TriangleAccessor::get_triangle_vertices_direct — shader/src/triangle_access.rs:18-60
     bool get_triangle(uint32_t index, V3* v0, V3* v1, V3* v2, uint32_t* mat) const {
@@ -341,6 +342,7 @@ struct Kernel {
 
     // BvhTraverser::traverse_and_intersect — shader/src/bvh.rs:18-88
     IntersectionResult traverse(const Ray& ray, float max_t) const {
+        if (fast) return traverse_fast(ray, max_t, false);
         if (sa.bvh_node_count() == 0) return miss();
         IntersectionResult result = miss();
         float closest_t = max_t;
@@ -377,6 +379,94 @@ struct Kernel {
             }
         }
         return result;
+    }
+
+    // ---- Baseline flavour (ii) of SURVEY 8(d): NOT the reference's algorithm.  The same node format walked the way
+    // a CPU ray tracer would: both children slab-tested at the parent against the closest hit so far, near child
+    // first, far child pushed.  Used only for the second CPU timing of bench.py ("what the host cores can do with a
+    // decent traversal") and checked to give the same image: equal t resolves to the lower triangle index, which
+    // is what the reference's own visiting order yields on its chunked BVH and on the brute-force path.
+    static bool slab_entry(V3 o, V3 inv, V3 bmin, V3 bmax, float limit, float* entry) {
+        V3 t1 = (bmin - o) * inv;
+        V3 t2 = (bmax - o) * inv;
+        V3 tmin = vmin(t1, t2);
+        V3 tmax = vmax(t1, t2);
+        float tmin_max = fmaxf(fmaxf(tmin.x, tmin.y), tmin.z);
+        float tmax_min = fminf(fminf(tmax.x, tmax.y), tmax.z);
+        if (!(tmax_min >= 0.0f && tmin_max <= tmax_min)) return false;
+        float e = fmaxf(tmin_max, 0.0f);
+        if (e > limit) return false; // <=: candidates at exactly the closest distance are still visited (tie rule)
+        *entry = e;
+        return true;
+    }
+    IntersectionResult traverse_fast(const Ray& ray, float max_t, bool any_hit) const {
+        const uint32_t n_nodes = sa.bvh_node_count();
+        if (n_nodes == 0) return miss();
+        const V3 o = ray.origin, d = ray.direction;
+        const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        IntersectionResult result = miss();
+        float closest_t = max_t, e;
+        uint32_t stack[128];
+        int sp = 0;
+        uint32_t node = 0;
+        c->node_visits++;
+        if (!slab_entry(o, inv, sa.node_min(0), sa.node_max(0), closest_t, &e)) return result;
+        for (;;) {
+            const uint32_t left = sa.node_left(node), right = sa.node_right(node);
+            bool descend = false;
+            if (left == 0xFFFFFFFFu) {
+                const uint32_t start = sa.node_tri_start(node), count = sa.node_tri_count(node);
+                for (uint32_t i = 0; i < count; i++) {
+                    if (start + i >= pc->metadata_offsets.triangle_indices_count) break;
+                    const uint32_t tri = sa.triangle_index(start + i);
+                    V3 v0, v1, v2;
+                    uint32_t mat;
+                    if (!get_triangle(tri, &v0, &v1, &v2, &mat)) continue;
+                    c->tri_tests++;
+                    IntersectionResult r = test_triangle(ray, v0, v1, v2, mat, tri, 3.402823466e+38f);
+                    if (!r.hit) continue;
+                    if (r.is.t < closest_t || (result.hit && r.is.t == closest_t && tri < result.is.prim_id)) {
+                        closest_t = r.is.t;
+                        result = r;
+                        if (any_hit) return result;
+                    }
+                }
+            } else {
+                float el = 0.0f, er = 0.0f;
+                const bool hl = left < n_nodes && slab_entry(o, inv, sa.node_min(left), sa.node_max(left), closest_t, &el);
+                const bool hr = right != 0xFFFFFFFFu && right < n_nodes && slab_entry(o, inv, sa.node_min(right), sa.node_max(right), closest_t, &er);
+                c->node_visits += 2;
+                if (hl && hr) {
+                    const bool left_first = el <= er;
+                    if (sp < 128) stack[sp++] = left_first ? right : left;
+                    node = left_first ? left : right;
+                    descend = true;
+                } else if (hl || hr) {
+                    node = hl ? left : right;
+                    descend = true;
+                }
+            }
+            if (descend) continue;
+            // next subtree whose box is still within reach (the closest hit may have moved since it was pushed)
+            bool found = false;
+            while (sp > 0) {
+                node = stack[--sp];
+                if (slab_entry(o, inv, sa.node_min(node), sa.node_max(node), closest_t, &e)) {
+                    found = true;
+                    break;
+                }
+            }
+            if (!found) break;
+        }
+        return result;
+    }
+    // any primitive strictly inside (MIN_RAY_DISTANCE, tmax)?  Same answer as `find_closest(ray).t < tmax`.
+    bool any_hit(const Ray& ray, float tmax) const {
+        c->rays++;
+        for (uint32_t i = 0; i < sa.sphere_count(); i++)
+            if (test_sphere(ray, sa, i, tmax).hit) return true;
+        if (pc->metadata_offsets.bvh_nodes_count > 0) return traverse_fast(ray, tmax, true).hit;
+        return brute_force(ray, tmax).hit;
     }
 
     // test_all_triangles_brute_force — shader/src/lib.rs:272-296
@@ -576,8 +666,11 @@ inline bool in_bounds(uint32_t idx, uint32_t idy, const rt_push_constants* pc) {
     return idx < tw && idy < th && px < width && py < height;
 }
 
+std::atomic<int> g_fast_traversal{0};
+
 Kernel make_kernel(const oracle_bindings* b, const rt_push_constants* pc, Counters* c) {
     Kernel k;
+    k.fast = g_fast_traversal.load() != 0;
     k.b = b;
     k.pc = pc;
     k.c = c;
@@ -688,8 +781,12 @@ struct ExtKernel {
                 }
                 Ray sr{is.point + is.normal * EXT_EPS, dir};
                 ec.shadow++;
-                IntersectionResult occ = k.find_closest(sr);
-                if (occ.hit && occ.is.t < tmax) continue; // occluded
+                if (k.fast) {
+                    if (k.any_hit(sr, tmax)) continue; // occluded (baseline flavour ii: same answer, found sooner)
+                } else {
+                    IntersectionResult occ = k.find_closest(sr);
+                    if (occ.hit && occ.is.t < tmax) continue; // occluded
+                }
             }
             total = total + contrib;
         }
@@ -969,3 +1066,6 @@ int oracle_render_extended(const oracle_bindings* b, const rt_push_constants* ba
 }
 
 } // extern "C"
+
+// Baseline flavour (ii) switch (process-wide): ordered, distance-culled traversal instead of the reference's.
+extern "C" void oracle_set_fast_traversal(int on) { g_fast_traversal.store(on ? 1 : 0); }

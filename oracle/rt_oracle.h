@@ -92,6 +92,12 @@ int oracle_render_extended(const oracle_bindings* b, const rt_push_constants* ba
 int oracle_build_bvh(const rt_triangle* tris, uint32_t n_tris, const rt_vertex* verts, uint32_t n_verts,
                      rt_bvh_node* nodes, uint32_t* n_nodes, uint32_t* tri_indices, uint32_t* n_indices);
 
+/* Baseline flavour (ii) of SURVEY 8(d) — NOT the reference's algorithm, used for a second CPU timing only: one
+ * triangle per leaf at every scene size, and an ordered, distance-culled traversal (same image: checked by the tests). */
+int oracle_build_bvh_per_triangle(const rt_triangle* tris, uint32_t n_tris, const rt_vertex* verts, uint32_t n_verts,
+                                  rt_bvh_node* nodes, uint32_t* n_nodes, uint32_t* tri_indices, uint32_t* n_indices);
+void oracle_set_fast_traversal(int on);
+
 /* f16 helpers used by the restatement (round-to-nearest-even), exposed for tests. */
 uint16_t oracle_f32_to_f16(float v);
 float oracle_f16_to_f32(uint16_t h);

@@ -138,8 +138,8 @@ struct StdBuild {
 
 } // namespace
 
-extern "C" int oracle_build_bvh(const rt_triangle* tris, uint32_t n_tris, const rt_vertex* verts, uint32_t n_verts,
-                                rt_bvh_node* out_nodes, uint32_t* n_nodes, uint32_t* out_indices, uint32_t* n_indices) {
+static int build_impl(const rt_triangle* tris, uint32_t n_tris, const rt_vertex* verts, uint32_t n_verts, rt_bvh_node* out_nodes, uint32_t* n_nodes,
+                      uint32_t* out_indices, uint32_t* n_indices, bool force_standard) {
     if (!n_nodes || !n_indices) return -1;
     for (uint32_t i = 0; i < n_tris; i++)
         if (tris[i].v0_index >= n_verts || tris[i].v1_index >= n_verts || tris[i].v2_index >= n_verts) return -1;
@@ -147,7 +147,7 @@ extern "C" int oracle_build_bvh(const rt_triangle* tris, uint32_t n_tris, const 
     std::vector<uint32_t> indices;
     if (n_tris == 0) { // :105-114
         nodes.push_back(node_leaf(aabb_empty(), 0, 0));
-    } else if (n_tris > 100000u) { // build_chunked :154-189
+    } else if (n_tris > 100000u && !force_standard) { // build_chunked :154-189
         size_t per_leaf = std::max<size_t>(n_tris / 10000u, 32);
         std::vector<rt_bvh_node> leaves;
         for (size_t base = 0, chunk_idx = 0; base < n_tris; base += per_leaf, chunk_idx++) {
@@ -186,4 +186,16 @@ extern "C" int oracle_build_bvh(const rt_triangle* tris, uint32_t n_tris, const 
     *n_nodes = (uint32_t)nodes.size();
     *n_indices = (uint32_t)indices.size();
     return 0;
+}
+
+extern "C" int oracle_build_bvh(const rt_triangle* tris, uint32_t n_tris, const rt_vertex* verts, uint32_t n_verts, rt_bvh_node* out_nodes,
+                                uint32_t* n_nodes, uint32_t* out_indices, uint32_t* n_indices) {
+    return build_impl(tris, n_tris, verts, n_verts, out_nodes, n_nodes, out_indices, n_indices, false);
+}
+
+// Baseline flavour (ii) only: one triangle per leaf at every size (the reference switches to 32+-triangle chunks above
+// 100,000 triangles, which is what makes its traversal slow there).
+extern "C" int oracle_build_bvh_per_triangle(const rt_triangle* tris, uint32_t n_tris, const rt_vertex* verts, uint32_t n_verts, rt_bvh_node* out_nodes,
+                                             uint32_t* n_nodes, uint32_t* out_indices, uint32_t* n_indices) {
+    return build_impl(tris, n_tris, verts, n_verts, out_nodes, n_nodes, out_indices, n_indices, true);
 }

@@ -92,3 +92,28 @@ def test_white_furnace_energy_bound(oracle_mod):
     r = oracle_mod.render_extended(p, 24, 24, 32, 6, camera=cam)
     assert r["rgb"].max() <= 0.1 * 20.0 + 1e-4  # russian roulette boosts single samples by at most 1/0.05
     np.testing.assert_allclose(r["rgb"].mean(), 0.1, rtol=0.15)
+
+
+def test_fast_traversal_flavour_gives_the_same_images(oracle_mod):
+    """bench.py times the CPU twice: the reference's traversal (no culling, 32+-triangle chunks above 100k triangles) and
+    a decent one (ordered, culled, one triangle per leaf).  The second is not the reference's algorithm, so it must at
+    least be shown to produce the same frames.  Comparator: the brute-force path (shader/src/lib.rs:272-296), whose
+    visiting order is the triangle order - the reference-format BVH of a <= 100k-triangle scene has an unpinned
+    topology and resolves equal-t ties (cornell12's shared edges) by it."""
+    from gpu_raytracer_amd import scenes
+    for scene, w, h in ((scenes.random_soup(3000, seed=9, size=0.4, n_spheres=2, n_lights=3), 48, 32), (scenes.cornell12(), 40, 40)):
+        brute = oracle_mod.PackedScene(scene, use_bvh=False)
+        fast = oracle_mod.PackedScene(scene, bvh=oracle_mod.build_bvh(scene.triangles, scene.vertices, per_triangle=True))
+        a = oracle_mod.render_extended(brute, w, h, 3, 2, frame_seed=5)
+        b1 = oracle_mod.render_frame(brute, w, h, mode=1)
+        oracle_mod.set_fast_traversal(True)
+        try:
+            c = oracle_mod.render_extended(fast, w, h, 3, 2, frame_seed=5)
+            d = oracle_mod.render_frame(fast, w, h, mode=1)
+        finally:
+            oracle_mod.set_fast_traversal(False)
+        np.testing.assert_array_equal(a["rgb"].view(np.uint32), c["rgb"].view(np.uint32))
+        assert a["segments"] == c["segments"]
+        np.testing.assert_array_equal(b1["rgb"].view(np.uint32), d["rgb"].view(np.uint32))
+        np.testing.assert_array_equal(b1["prim"], d["prim"])
+        assert d["counters"]["tri_tests"] < b1["counters"]["tri_tests"]
