@@ -352,7 +352,12 @@ void build_bvh(const BuildTri* tris_in, size_t n_in, const BvhBuildOptions& opt_
         }
         d.ex_off = ex[0] | (ex[1] << 8) | (ex[2] << 16) | ((child_off & 0xFFu) << 24);
         d.base_off = (node_base & RT_DEV_NODE_BASE_MASK) | ((child_off >> 8) << 24);
-        d.tri_inf = (tri_base & RT_DEV_TRI_BASE_MASK) | ((uint32_t)n_inner << 27);
+        // Absent child slots (inverted boxes) decode to `LEAF | tri_base + 0`.  They are never entered as long as the float
+        // evaluation can tell 255 grid steps apart, which fails for a degenerate node (all extents zero) or a ray origin
+        // ~1e8 grid steps away; make that case harmless: the reference must then still name a real leaf (the node's first
+        // leaf, or triangle 0 — always the start of a leaf — when it has none): a redundant triangle test, never a bad read.
+        const uint32_t safe_tri_base = n_inner < nch ? tri_base : 0u;
+        d.tri_inf = (safe_tri_base & RT_DEV_TRI_BASE_MASK) | ((uint32_t)n_inner << 27);
     }
     out.root_ref = 0;
     out.sah_cost = cost;

@@ -322,19 +322,26 @@ int ensure_wavefront(rt_ctx* ctx, DeviceState& d, uint32_t n_blocks, uint32_t ba
 // of the 288 GB) 5,840.  Target 64 M paths, bounded by half the free device memory, the 27-bit path id of a shadow
 // queue entry and the 32-bit queue positions; the samples are then spread evenly over the batches.
 // RT_WF_BATCH (samples per batch) / RT_WF_TARGET_PATHS override.
+// Largest number of path slots the wavefront pipeline can address: 27-bit path ids in shadow queue entries, 32-bit queue
+// positions with up to 2.5 slots per (path, light).
+uint64_t wavefront_max_paths(uint32_t n_lights) {
+    const uint64_t lights = std::max(1u, n_lights);
+    return std::min<uint64_t>((uint64_t)RT_WF_ID_MASK + 1, (1ull << 30) / lights);
+}
+
 uint32_t wavefront_batch(uint32_t n_blocks, uint32_t spp, uint32_t n_lights, size_t free_bytes) {
+    const uint64_t per_sample = std::max<uint64_t>(1, (uint64_t)n_blocks * 64u);
+    const uint64_t hard_limit = std::max<uint64_t>(1, wavefront_max_paths(n_lights) / per_sample); // samples per batch the ids allow
     if (const char* e = std::getenv("RT_WF_BATCH")) {
         const uint32_t want = (uint32_t)std::strtoul(e, nullptr, 10);
-        if (want) return std::max(1u, std::min(want, spp));
+        if (want) return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min(want, spp), hard_limit));
     }
     uint64_t target_paths = 64ull << 20;
     if (const char* e = std::getenv("RT_WF_TARGET_PATHS")) target_paths = std::max<uint64_t>(1, std::strtoull(e, nullptr, 10));
     const uint64_t lights = std::max(1u, n_lights);
     const uint64_t bytes_per_path = 8 * 16 + 4 + 4 + 2 * 10 + 10 * lights; // path state, vis, pxy, two extension queues, shadow queue (2.5 slots per entry)
     target_paths = std::min<uint64_t>(target_paths, free_bytes / 2 / bytes_per_path);
-    target_paths = std::min<uint64_t>(target_paths, (uint64_t)RT_WF_ID_MASK + 1);
-    target_paths = std::min<uint64_t>(target_paths, (1ull << 30) / lights); // queue positions are 32-bit: 2.5 x paths x lights slots
-    const uint64_t per_sample = std::max<uint64_t>(1, (uint64_t)n_blocks * 64u);
+    target_paths = std::min<uint64_t>(target_paths, wavefront_max_paths(n_lights));
     const uint32_t max_batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(spp, target_paths / per_sample));
     const uint32_t n_batches = (spp + max_batch - 1) / max_batch;
     return std::max(1u, (spp + n_batches - 1) / std::max(1u, n_batches));
@@ -362,8 +369,11 @@ int run_frame(rt_ctx* ctx, DevFrame fr, bool counters, uint32_t world, uint32_t 
         }
         HIPCHK(ctx, hipMemsetAsync(d.counters, 0, 16 * sizeof(unsigned long long), d.stream));
         HIPCHK(ctx, hipEventRecord(d.ev0, d.stream));
+        // the queue-based pipeline needs one visibility bit per light and every path slot of ONE sample per owned pixel block
+        // addressable; anything else (more than 32 lights, a single device's share beyond ~134 M pixels) takes the megakernel
         const bool wavefront = f.mode == RT_MODE_EXTENDED && !(f.flags & (RT_FLAG_KERNEL_V1 | RT_FLAG_KERNEL_SM)) &&
-                               ctx->scene_counts.n_lights <= RT_WF_MAX_LIGHTS;
+                               ctx->scene_counts.n_lights <= RT_WF_MAX_LIGHTS &&
+                               (uint64_t)f.n_owned_tiles * rt::blocks_per_tile(f.tile_size) * 64u <= wavefront_max_paths(ctx->scene_counts.n_lights);
         if (wavefront) {
             const uint32_t n_blocks = f.n_owned_tiles * rt::blocks_per_tile(f.tile_size);
             size_t free_b = 0, total_b = 0;

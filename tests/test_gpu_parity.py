@@ -265,3 +265,40 @@ def test_bistro_like_vs_faithful_oracle(gpu_ctx, oracle_mod):
     gpu_ctx.render(3840, 2160, scene.camera, mode=1)
     np.testing.assert_array_equal(gpu_ctx.read_rgb32f().view(np.uint32), a.view(np.uint32))
     assert np.isfinite(a).all() and (prim != 0xFFFFFFFF).mean() > 0.5
+
+
+def test_degenerate_nodes_and_far_origins_are_safe_and_exact(gpu_ctx, oracle_mod):
+    """The quantised boxes are filters and absent child slots are inverted boxes the float evaluation must tell apart:
+    that breaks down for a node of zero extent (many zero-area triangles in one point) and for a ray origin ~1e8 grid
+    steps away from a small node.  Both must stay correct (the triangle test decides) and must not read out of bounds
+    (absent slots decode to a real leaf, bvh_builder.cpp)."""
+    import dataclasses
+    base = scenes.random_soup(900, seed=12, size=0.5, n_spheres=1, n_lights=2)
+    # 64 zero-area triangles in one point + 64 more collapsed onto a line
+    nv = len(base.vertices)
+    extra_v = np.zeros(2, dtype=base.vertices.dtype)
+    extra_v["position"][0] = (0.25, 0.5, -0.75)
+    extra_v["position"][1] = (0.25, 0.5, -0.25)
+    extra_t = np.zeros(128, dtype=base.triangles.dtype)
+    for k in ("v0_index", "v1_index", "v2_index"):
+        extra_t[k][:64] = nv
+    extra_t["v0_index"][64:] = nv
+    extra_t["v1_index"][64:] = nv + 1
+    extra_t["v2_index"][64:] = nv + 1
+    scene = dataclasses.replace(base, vertices=np.concatenate([base.vertices, extra_v]), triangles=np.concatenate([base.triangles, extra_t]))
+    w, h = 160, 96
+    ref = oracle_mod.render_frame(oracle_mod.PackedScene(scene, use_bvh=False), w, h)
+    _assert_bit_exact(_render_gpu(gpu_ctx, scene, w, h), ref)
+    # the same scene seen from 2e7 units away through a very narrow lens
+    cam = scene.camera.copy()
+    cam["position"] = (0.0, 0.0, 2.0e7)
+    cam["direction"] = (0.0, 0.0, -1.0)
+    cam["fov"] = 2.0e-5
+    ref = oracle_mod.render_frame(oracle_mod.PackedScene(scene, use_bvh=False), w, h, camera=cam)
+    gpu = _render_gpu(gpu_ctx, scene, w, h, camera=cam)
+    _assert_bit_exact(gpu, ref)
+    assert (ref["prim"] != 0xFFFFFFFF).any()
+    # extended mode on the same inputs: no fault, same bits as the CPU statement
+    ext = oracle_mod.render_extended(oracle_mod.PackedScene(scene, use_bvh=False), 64, 40, 2, 2, camera=cam)
+    gpu_ctx.render(64, 40, cam, mode=2, spp=2, max_bounces=2)
+    np.testing.assert_array_equal(gpu_ctx.read_rgb32f().view(np.uint32), ext["rgb"].view(np.uint32))
