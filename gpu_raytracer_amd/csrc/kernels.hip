@@ -14,6 +14,8 @@
 // the reference's own test applied to our boxes plus culling by the closest hit.
 #include "kernels.h"
 
+#include <algorithm>
+
 #include "device_common.h"
 
 using namespace rtdev;
@@ -621,9 +623,37 @@ namespace rt {
 
 static size_t lds_bytes(const DevScene& sc) { return (size_t)(sc.stack_entries + 3u) * WAVE * sizeof(uint32_t); } // +3: visit_node4 stores three words unconditionally
 
+__global__ __launch_bounds__(256) void k_combine_rgba8(const uint32_t* __restrict__ red, const uint32_t* __restrict__ green, const uint32_t* __restrict__ blue,
+                                                        uint32_t* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = (red[i] & 0x000000FFu) | (green[i] & 0x0000FF00u) | (blue[i] & 0x00FF0000u) | 0xFF000000u;
+}
+__global__ __launch_bounds__(256) void k_pack_rgb32f(const float4* __restrict__ rgba, float* __restrict__ rgb, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = rgba[i];
+        rgb[3 * i + 0] = v.x;
+        rgb[3 * i + 1] = v.y;
+        rgb[3 * i + 2] = v.z;
+    }
+}
+
 uint32_t blocks_per_tile(uint32_t tile_size) {
     uint32_t b = (tile_size + 7u) >> 3;
     return b * b;
+}
+
+hipError_t launch_combine_rgba8(const uint8_t* red, const uint8_t* green, const uint8_t* blue, uint8_t* out, size_t n_pixels, hipStream_t stream) {
+    if (n_pixels == 0) return hipSuccess;
+    const unsigned grid = (unsigned)std::min<size_t>((n_pixels + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_combine_rgba8, dim3(grid), dim3(256), 0, stream, reinterpret_cast<const uint32_t*>(red), reinterpret_cast<const uint32_t*>(green),
+                       reinterpret_cast<const uint32_t*>(blue), reinterpret_cast<uint32_t*>(out), n_pixels);
+    return hipGetLastError();
+}
+hipError_t launch_pack_rgb32f(const float* rgba, float* rgb, size_t n_pixels, hipStream_t stream) {
+    if (n_pixels == 0) return hipSuccess;
+    const unsigned grid = (unsigned)std::min<size_t>((n_pixels + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_pack_rgb32f, dim3(grid), dim3(256), 0, stream, reinterpret_cast<const float4*>(rgba), rgb, n_pixels);
+    return hipGetLastError();
 }
 
 hipError_t launch_render_reference(const DevScene& sc, const DevFrame& fr, const DevTargets& tg, bool counters, hipStream_t stream) {

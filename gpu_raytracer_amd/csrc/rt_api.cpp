@@ -41,6 +41,9 @@ struct DeviceState {
     float* hit_t = nullptr;
     unsigned long long* counters = nullptr;
     uint32_t fb_w = 0, fb_h = 0;
+    void* readback_dev = nullptr;  // epilogue output (combined rgba8 / packed rgb32f), whole-frame single-device reads
+    void* readback_host = nullptr; // pinned staging for it
+    size_t readback_bytes = 0;
     uint32_t tile_first = 0, tile_stride = 1, n_owned = 0; // of the last rt_render
     rt::WfBuffers wf{};                                    // wavefront pipeline state (extended mode)
     bool used_wavefront = false;
@@ -97,6 +100,10 @@ void free_targets(DeviceState& d) {
     (void)hipFree(d.rgba32f); (void)hipFree(d.chan[0]); (void)hipFree(d.chan[1]); (void)hipFree(d.chan[2]); (void)hipFree(d.prim_id); (void)hipFree(d.hit_t);
     d.rgba32f = nullptr; d.chan[0] = d.chan[1] = d.chan[2] = nullptr; d.prim_id = nullptr; d.hit_t = nullptr;
     d.fb_w = d.fb_h = 0;
+    (void)hipFree(d.readback_dev);
+    if (d.readback_host) (void)hipHostFree(d.readback_host);
+    d.readback_dev = d.readback_host = nullptr;
+    d.readback_bytes = 0;
 }
 
 void free_wavefront(DeviceState& d) {
@@ -698,13 +705,40 @@ static int gather(rt_ctx* ctx, uint8_t* out, size_t elem, int which /*0 rgba32f,
     return RT_OK;
 }
 
+// Whole frame on one device: run the epilogue there and bring the result back through pinned staging
+// (`which` 0: packed rgb32f, 1: combined rgba8).  Returns RT_OK, an error, or 1 when the caller must use the gather path.
+static int read_epilogue(rt_ctx* ctx, int which, void* out, size_t bytes) {
+    if (ctx->devs.size() != 1) return 1;
+    DeviceState& d = ctx->devs[0];
+    if (d.fb_w != ctx->frame_w || d.fb_h != ctx->frame_h || !(d.tile_stride == 1 && d.tile_first == 0)) return 1;
+    HIPCHK(ctx, hipSetDevice(d.device));
+    if (d.readback_bytes < bytes) {
+        (void)hipFree(d.readback_dev);
+        if (d.readback_host) (void)hipHostFree(d.readback_host);
+        d.readback_dev = d.readback_host = nullptr;
+        d.readback_bytes = 0;
+        HIPCHK(ctx, hipMalloc(&d.readback_dev, bytes));
+        HIPCHK(ctx, hipHostMalloc(&d.readback_host, bytes, hipHostMallocDefault));
+        d.readback_bytes = bytes;
+    }
+    const size_t n = (size_t)ctx->frame_w * ctx->frame_h;
+    if (which == 0) HIPCHK(ctx, rt::launch_pack_rgb32f(d.rgba32f, (float*)d.readback_dev, n, d.stream));
+    else HIPCHK(ctx, rt::launch_combine_rgba8(d.chan[0], d.chan[1], d.chan[2], (uint8_t*)d.readback_dev, n, d.stream));
+    HIPCHK(ctx, hipMemcpyAsync(d.readback_host, d.readback_dev, bytes, hipMemcpyDeviceToHost, d.stream));
+    HIPCHK(ctx, hipStreamSynchronize(d.stream));
+    std::memcpy(out, d.readback_host, bytes);
+    return RT_OK;
+}
+
 int rt_read_rgb32f(rt_ctx* ctx, float* out, size_t n_floats) {
     if (!ctx) return RT_ERR_BAD_ARG;
     if (!ctx->frame_valid) return ctx->fail(RT_ERR_NOT_UPLOADED, "rt_read_rgb32f: nothing rendered yet");
     size_t n = (size_t)ctx->frame_w * ctx->frame_h;
     if (!out || n_floats != n * 3) return ctx->fail(RT_ERR_BAD_ARG, "rt_read_rgb32f: expected %zu floats, got %zu", n * 3, n_floats);
+    int rc = read_epilogue(ctx, 0, out, n * 12);
+    if (rc <= 0) return rc;
     std::vector<float> tmp(n * 4, 0.0f);
-    int rc = gather(ctx, reinterpret_cast<uint8_t*>(tmp.data()), 16, 0);
+    rc = gather(ctx, reinterpret_cast<uint8_t*>(tmp.data()), 16, 0);
     if (rc != RT_OK) return rc;
     for (size_t i = 0; i < n; i++) {
         out[3 * i + 0] = tmp[4 * i + 0];
@@ -734,8 +768,10 @@ int rt_read_rgba8_combined(rt_ctx* ctx, uint8_t* out, size_t n_bytes) {
     if (!ctx->frame_valid) return ctx->fail(RT_ERR_NOT_UPLOADED, "rt_read_rgba8_combined: nothing rendered yet");
     size_t n = (size_t)ctx->frame_w * ctx->frame_h * 4;
     if (!out || n_bytes != n) return ctx->fail(RT_ERR_BAD_ARG, "rt_read_rgba8_combined: expected %zu bytes, got %zu", n, n_bytes);
+    int rc = read_epilogue(ctx, 1, out, n);
+    if (rc <= 0) return rc;
     std::vector<uint8_t> r(n), g(n), b(n);
-    int rc = rt_read_rgba8_channels(ctx, r.data(), g.data(), b.data(), n);
+    rc = rt_read_rgba8_channels(ctx, r.data(), g.data(), b.data(), n);
     if (rc != RT_OK) return rc;
     for (size_t i = 0; i < n; i += 4) { // main_fs, shader/src/lib.rs:383-388
         out[i + 0] = r[i + 0];
