@@ -1,0 +1,173 @@
+// Structural validator for the 4-wide quantised tree of gpu_raytracer_amd/csrc/bvh_builder.cpp (host code; built by
+// tests/test_device_bvh.py with AddressSanitizer + UBSan).  It decodes nodes exactly as visit_node4 does and checks
+// what the kernels rely on:
+//   * every child reference names a node / triangle inside the arrays - including the slots of ABSENT children,
+//     which a degenerate float evaluation may enter (they must decode to a real leaf);
+//   * every input triangle with finite coordinates appears in exactly one leaf, leaves hold 1..4 triangles, the run
+//     length sits in the first record of the leaf and only there;
+//   * every triangle lies inside the dequantised box of every ancestor's child slot (the boxes are conservative);
+//   * the reported depth bounds the real one and stays within the stack the kernels provide.
+// usage: check_bvh <n_triangles> <seed> <kind>   kind: 0 soup, 1 coplanar grid, 2 coincident points, 3 collinear chain,
+//                                                      4 huge + tiny mixed, 5 with NaN / inf vertices
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <random>
+#include <vector>
+
+#include "bvh_builder.h"
+
+using namespace rt;
+
+static int g_fail = 0;
+#define CHECK(cond, ...)                       \
+    do {                                       \
+        if (!(cond)) {                         \
+            if (g_fail < 20) {                 \
+                std::printf("FAIL: " __VA_ARGS__); \
+                std::printf("\n");             \
+            }                                  \
+            g_fail++;                          \
+        }                                      \
+    } while (0)
+
+struct Ctx {
+    const BvhBuild* b;
+    std::vector<uint32_t> seen; // per prim id
+    uint32_t max_depth = 0;
+    size_t leaves = 0;
+};
+
+static void check_leaf(Ctx& c, uint32_t ref, const double lo[3], const double hi[3], bool have_box) {
+    const uint32_t start = ref & RT_DEV_LEAF_START_MASK;
+    CHECK(start < c.b->tris.size(), "leaf start %u out of %zu", start, c.b->tris.size());
+    if (start >= c.b->tris.size()) return;
+    const uint32_t count = c.b->tris[start].leaf_count;
+    CHECK(count >= 1 && count <= RT_DEV_MAX_LEAF_TRIS, "leaf at %u has count %u", start, count);
+    CHECK((size_t)start + count <= c.b->tris.size(), "leaf at %u runs past the array", start);
+    if (count < 1 || (size_t)start + count > c.b->tris.size()) return;
+    c.leaves++;
+    for (uint32_t i = 0; i < count; i++) {
+        const DevTri& t = c.b->tris[start + i];
+        if (i > 0) CHECK(t.leaf_count == 0, "triangle %u inside a leaf carries a count", start + i);
+        CHECK(t.prim_id < c.seen.size(), "prim id %u out of range", t.prim_id);
+        if (t.prim_id < c.seen.size()) c.seen[t.prim_id]++;
+        if (!have_box) continue;
+        for (int v = 0; v < 3; v++)
+            for (int a = 0; a < 3; a++) {
+                const double p = v == 0 ? (double)t.v0[a] : v == 1 ? (double)t.v0[a] + (double)t.e1[a] : (double)t.v0[a] + (double)t.e2[a];
+                // e1 / e2 are rounded differences: allow the vertex to stick out by one float ulp of its magnitude
+                const double tol = std::ldexp(std::fabs(p) + std::fabs((double)t.v0[a]), -22);
+                CHECK(p >= lo[a] - tol && p <= hi[a] + tol, "triangle %u vertex %d axis %d: %.9g outside [%.9g, %.9g]", start + i, v, a, p, lo[a], hi[a]);
+            }
+    }
+}
+
+static void check_node(Ctx& c, uint32_t node, uint32_t depth, const double plo[3], const double phi[3], bool have_box) {
+    CHECK(node < c.b->nodes.size(), "node %u out of %zu", node, c.b->nodes.size());
+    if (node >= c.b->nodes.size()) return;
+    c.max_depth = depth > c.max_depth ? depth : c.max_depth;
+    CHECK(depth <= RT_DEV_MAX_BVH_DEPTH, "depth %u beyond the bound", depth);
+    if (depth > RT_DEV_MAX_BVH_DEPTH) return;
+    const DevNode4& n = c.b->nodes[node];
+    const uint32_t child_off = (n.ex_off >> 24) | ((n.base_off >> 16) & 0xFF00u);
+    const uint32_t base_inner = n.base_off & RT_DEV_NODE_BASE_MASK;
+    const uint32_t base_leaf = (n.tri_inf & RT_DEV_TRI_BASE_MASK) | RT_DEV_LEAF_FLAG;
+    const uint32_t n_inner = (n.tri_inf >> 27) & 7u;
+    CHECK(n_inner <= 4, "node %u: n_inner %u", node, n_inner);
+    double scale[3];
+    for (int a = 0; a < 3; a++) {
+        const uint32_t e = (n.ex_off >> (8 * a)) & 0xFFu;
+        CHECK(e >= 1 && e <= 254, "node %u axis %d exponent %u", node, a, e);
+        scale[a] = std::ldexp(1.0, (int)e - 127);
+    }
+    int present = 0;
+    for (int s = 0; s < 4; s++) {
+        double lo[3], hi[3];
+        bool absent = false;
+        for (int a = 0; a < 3; a++) {
+            const uint32_t qlo = (n.qlo[a] >> (8 * s)) & 0xFFu, qhi = (n.qhi[a] >> (8 * s)) & 0xFFu;
+            if (qlo > qhi) absent = true;
+            lo[a] = (double)n.org[a] + qlo * scale[a];
+            hi[a] = (double)n.org[a] + qhi * scale[a];
+        }
+        const uint32_t off = (child_off >> (4 * s)) & 15u;
+        const uint32_t ref = ((uint32_t)s < n_inner ? base_inner : base_leaf) + off;
+        if (absent) { // may be entered by a degenerate evaluation: must still be a readable leaf
+            CHECK((uint32_t)s >= n_inner, "node %u: inner slot %d is absent", node, s);
+            const uint32_t start = ref & RT_DEV_LEAF_START_MASK;
+            CHECK((ref & RT_DEV_LEAF_FLAG) && start < c.b->tris.size() && c.b->tris[start].leaf_count >= 1 &&
+                      (size_t)start + c.b->tris[start].leaf_count <= c.b->tris.size(),
+                  "node %u: absent slot %d decodes to an unreadable leaf (start %u)", node, s, start);
+            continue;
+        }
+        present++;
+        if (have_box)
+            for (int a = 0; a < 3; a++) { // a child's box may stick out of its parent's by the quantisation step, not more
+                CHECK(lo[a] >= plo[a] - 2 * scale[a] - 1e-30 && hi[a] <= phi[a] + 2 * scale[a] + 1e-30, "node %u slot %d axis %d box [%.9g,%.9g] far outside parent [%.9g,%.9g]",
+                      node, s, a, lo[a], hi[a], plo[a], phi[a]);
+            }
+        if (ref & RT_DEV_LEAF_FLAG) check_leaf(c, ref, lo, hi, true);
+        else check_node(c, ref, depth + 1, lo, hi, true);
+    }
+    CHECK(present >= 2, "node %u has %d children", node, present);
+}
+
+int main(int argc, char** argv) {
+    const size_t n = argc > 1 ? (size_t)std::atoll(argv[1]) : 1000;
+    const uint32_t seed = argc > 2 ? (uint32_t)std::atoi(argv[2]) : 1;
+    const int kind = argc > 3 ? std::atoi(argv[3]) : 0;
+    std::mt19937 rng(seed);
+    std::uniform_real_distribution<float> u(-1.0f, 1.0f);
+    std::vector<BuildTri> tris(n);
+    size_t n_finite = 0;
+    for (size_t i = 0; i < n; i++) {
+        BuildTri& t = tris[i];
+        t.material_id = (uint32_t)(i % 5);
+        t.prim_id = (uint32_t)i;
+        float c[3] = {u(rng) * 10, u(rng) * 10, u(rng) * 10}, s = 0.3f;
+        if (kind == 1) c[2] = -3.0f;
+        if (kind == 2) c[0] = c[1] = c[2] = 1.25f, s = 0.0f;
+        if (kind == 3) c[0] = std::pow(1.001f, (float)i), c[1] = 0.0f, c[2] = 0.0f, s = 1e-3f;
+        if (kind == 4) s = (i % 97 == 0) ? 1e5f : 1e-4f;
+        for (int a = 0; a < 3; a++) {
+            t.v0[a] = c[a] + u(rng) * s;
+            t.v1[a] = c[a] + u(rng) * s;
+            t.v2[a] = c[a] + u(rng) * s;
+            if (kind == 1 && a == 2) t.v0[a] = t.v1[a] = t.v2[a] = -3.0f;
+        }
+        if (kind == 5 && i % 7 == 0) t.v1[i % 3] = (i % 14 == 0) ? std::numeric_limits<float>::quiet_NaN() : std::numeric_limits<float>::infinity();
+        bool finite = true;
+        for (int a = 0; a < 3; a++) finite = finite && std::isfinite(t.v0[a]) && std::isfinite(t.v1[a]) && std::isfinite(t.v2[a]);
+        n_finite += finite ? 1 : 0;
+    }
+    BvhBuild b;
+    build_bvh(tris.data(), tris.size(), BvhBuildOptions(), b);
+    Ctx c;
+    c.b = &b;
+    c.seen.assign(n, 0);
+    CHECK(b.tris.size() == n_finite, "%zu triangles emitted, %zu finite", b.tris.size(), n_finite);
+    const double inf = std::numeric_limits<double>::infinity();
+    const double lo[3] = {-inf, -inf, -inf}, hi[3] = {inf, inf, inf};
+    if (n_finite == 0) {
+        CHECK(b.nodes.empty() && b.root_ref == RT_DEV_REF_NONE, "empty build has nodes");
+    } else if (b.root_ref & RT_DEV_LEAF_FLAG) {
+        check_leaf(c, b.root_ref, lo, hi, false);
+    } else {
+        check_node(c, b.root_ref, 1, lo, hi, false);
+    }
+    size_t once = 0;
+    for (size_t i = 0; i < n; i++) {
+        bool finite = true;
+        for (int a = 0; a < 3; a++) finite = finite && std::isfinite(tris[i].v0[a]) && std::isfinite(tris[i].v1[a]) && std::isfinite(tris[i].v2[a]);
+        CHECK(c.seen[i] == (finite ? 1u : 0u), "triangle %zu appears %u times", i, c.seen[i]);
+        once += c.seen[i] == 1;
+    }
+    CHECK(c.max_depth <= b.depth, "real depth %u exceeds the reported %u", c.max_depth, b.depth);
+    CHECK(3 * b.depth + 1 <= RT_DEV_MAX_STACK_ENTRIES, "depth %u needs more stack than the kernels provide", b.depth);
+    std::printf("kind %d n %zu: %zu nodes, %zu leaves, depth %u (reported %u), %zu triangles placed, %d failures\n", kind, n, b.nodes.size(), c.leaves, c.max_depth,
+                b.depth, once, g_fail);
+    return g_fail ? 1 : 0;
+}

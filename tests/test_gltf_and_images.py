@@ -200,3 +200,66 @@ def test_native_front_end_renders_the_gltf_fixture_like_the_oracle(oracle_mod, t
     img2 = np.frombuffer(raw2[len(b"P6\n160 120\n255\n"):], np.uint8).reshape(120, 160, 3)
     exp = np.clip(np.floor(np.clip(ext["rgb"], 0, 1) * 255.0 + 0.5), 0, 255).astype(np.uint8)
     np.testing.assert_array_equal(img2, exp)
+
+
+def test_loader_survives_mutated_files_under_asan_ubsan(tmp_path):
+    """The loader parses untrusted files: 600 deterministic mutations of the fixtures (byte flips, deletions,
+    duplications, truncation, hostile numbers, stray JSON punctuation) through an AddressSanitizer + UBSan build of the
+    header-only loader (tests/fuzz_gltf.cpp).  Every input must be either loaded or rejected with a GltfError."""
+    import random
+    import re
+    import shutil
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    exe = tmp_path / "fuzz_gltf"
+    cc = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-I" + os.path.join(root, "include"),
+                         "-I" + os.path.join(root, "gpu_raytracer_amd", "csrc"), os.path.join(here, "fuzz_gltf.cpp"), "-o", str(exe)],
+                        capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr[-2000:]
+    rnd = random.Random(20240607)
+
+    def mutate(b):
+        b = bytearray(b)
+        if len(b) < 4:
+            return bytes(b)
+        k = rnd.choice(["flip", "del", "dup", "num", "trunc", "ins"])
+        if k == "flip":
+            for _ in range(rnd.randint(1, 8)):
+                b[rnd.randrange(len(b))] = rnd.randrange(256)
+        elif k == "del":
+            i = rnd.randrange(len(b))
+            del b[i:min(len(b), i + rnd.randint(1, 64))]
+        elif k == "dup":
+            i = rnd.randrange(len(b))
+            b[i:i] = b[i:min(len(b), i + rnd.randint(1, 64))]
+        elif k == "num":
+            s = bytes(b)
+            ms = list(re.finditer(rb"\d+", s))
+            if ms:
+                m = rnd.choice(ms)
+                b = bytearray(s[:m.start()] + rnd.choice([b"0", b"-1", b"4294967295", b"99999999999999999999", b"1e309", b"2147483648", b"65536", b"3"]) + s[m.end():])
+        elif k == "trunc":
+            b = b[:rnd.randrange(len(b))]
+        else:
+            i = rnd.randrange(len(b))
+            b[i:i] = rnd.choice([b"{", b"}", b"[", b"]", b'"', b",", b":", b"\\", b"\x00", b"null", b"true"])
+        return bytes(b)
+
+    shutil.copy(os.path.join(GOLD, "modes.bin"), tmp_path / "modes.bin")
+    files = []
+    for name in ("cornell12.gltf", "cornell12.glb", "modes.gltf"):
+        data = open(os.path.join(GOLD, name), "rb").read()
+        stem, ext = name.split(".")
+        for i in range(200):
+            d = data
+            for _ in range(rnd.randint(1, 3)):
+                d = mutate(d)
+            p = tmp_path / f"{stem}_{i}.{ext}"
+            p.write_bytes(d)
+            files.append(str(p))
+    env = dict(os.environ, UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1", ASAN_OPTIONS="detect_leaks=1")
+    run = subprocess.run([str(exe)] + files, capture_output=True, text=True, env=env, timeout=600)
+    assert run.returncode == 0, run.stderr[-4000:]
+    m = re.search(r"loaded (\d+), rejected (\d+)", run.stdout)
+    assert m and int(m.group(1)) + int(m.group(2)) == len(files) and int(m.group(2)) > 100 and int(m.group(1)) > 5
