@@ -328,7 +328,7 @@ void build_bvh(const BuildTri* tris_in, size_t n_in, const BvhBuildOptions& opt_
                 if (e < 1) e = 1;
                 if (e > 254) e = 254;
             }
-            ex[a] = (uint32_t)e;
+            ex[a] = (uint32_t)(e - 127) & 0xFFu; // stored as a signed byte k: plane = org + q * 2^k
             const double scale = std::ldexp(1.0, e - 127);
             uint32_t lo_word = 0, hi_word = 0;
             for (int c = 0; c < 4; c++) {

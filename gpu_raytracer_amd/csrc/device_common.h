@@ -186,7 +186,6 @@ __device__ __forceinline__ bool test_leaf(const DevTri* __restrict__ tris, uint3
 #endif
 struct FilterRay { // per-segment constants of the box filter
     V3 o, inv;     // inv = 1/d with |d| clamped away from zero (a filter may do that; the triangle test uses the real d)
-    V3 err;        // RT_FILTER_SLACK * |inv|: scale of the conservative widening, see visit_node4
 };
 __device__ __forceinline__ FilterRay make_filter_ray(V3 o, V3 d) {
     FilterRay f;
@@ -201,7 +200,6 @@ __device__ __forceinline__ FilterRay make_filter_ray(V3 o, V3 d) {
 #else
     f.inv = v3(1.0f / dx, 1.0f / dy, 1.0f / dz);
 #endif
-    f.err = v3(fabsf(f.inv.x) * RT_FILTER_SLACK, fabsf(f.inv.y) * RT_FILTER_SLACK, fabsf(f.inv.z) * RT_FILTER_SLACK);
     return f;
 }
 
@@ -244,24 +242,27 @@ __device__ __forceinline__ bool visit_node4(const uint4* __restrict__ nodes, con
     const uint4* n = nodes + (size_t)cur * 3;
     const uint4 w0 = n[0], w1 = n[1], w2 = n[2];
     if (COUNT) cnt.nodes++;
-    const float scx = __uint_as_float((w0.w << 23) & 0x7F800000u), scy = __uint_as_float((w0.w << 15) & 0x7F800000u),
-                scz = __uint_as_float((w0.w << 7) & 0x7F800000u);
+    // grid scale 2^k per axis, k a signed byte: a = scale / d as one ldexp of the ray's reciprocal (exact)
+    const float ax = ldexpf(fr.inv.x, (int)(int8_t)(w0.w & 0xFFu)), ay = ldexpf(fr.inv.y, (int)(int8_t)((w0.w >> 8) & 0xFFu)),
+                az = ldexpf(fr.inv.z, (int)(int8_t)((w0.w >> 16) & 0xFFu));
     const float dox = __uint_as_float(w0.x) - fr.o.x, doy = __uint_as_float(w0.y) - fr.o.y, doz = __uint_as_float(w0.z) - fr.o.z;
-    const float ax = scx * fr.inv.x, ay = scy * fr.inv.y, az = scz * fr.inv.z;
     const float bx = dox * fr.inv.x, by = doy * fr.inv.y, bz = doz * fr.inv.z;
-    const float ex = fmaf(255.0f, scx, fabsf(dox)) * fr.err.x; // fr.err = RT_FILTER_SLACK * |inv|
-    const float ey = fmaf(255.0f, scy, fabsf(doy)) * fr.err.y;
-    const float ez = fmaf(255.0f, scz, fabsf(doz)) * fr.err.z;
-    // The widening stays per axis: a ray almost parallel to an axis has an enormous |b| (and error bound) on that axis
-    // only.  One bound for the whole interval test (tmin - 2E <= tmax with E summed over the axes) is 5 instructions
-    // cheaper and 26 % slower: the degenerate axis inflates every box.  Measurement: without any widening the frame
-    // is 3.7 % faster (RT_EXPERIMENT_NO_WIDENING; not conservative).
-    // (near, far) pairs: one packed fma per child and axis
+    // widening per axis: RT_FILTER_SLACK * (|b| + 255 |a|), see above.  It stays per axis: a ray almost parallel to an
+    // axis has an enormous |b| (and error bound) on that axis only; one bound for the whole interval test
+    // (tmin - 2E <= tmax, E summed over the axes) is 5 instructions cheaper and 26 % slower because the degenerate axis
+    // inflates every box.  Without any widening the frame is 3.7 % faster (RT_EXPERIMENT_NO_WIDENING; not conservative).
+    const float ex = fmaf(255.0f, fabsf(ax), fabsf(bx)) * RT_FILTER_SLACK;
+    const float ey = fmaf(255.0f, fabsf(ay), fabsf(by)) * RT_FILTER_SLACK;
+    const float ez = fmaf(255.0f, fabsf(az), fabsf(bz)) * RT_FILTER_SLACK;
+    // (near, far) pairs (b - e, b + e) as one packed fma each; then one packed fma per child and axis
 #if RT_EXPERIMENT_NO_WIDENING
     const f32x2 bx2 = {bx, bx}, by2 = {by, by}, bz2 = {bz, bz};
     (void)ex; (void)ey; (void)ez;
 #else
-    const f32x2 bx2 = {bx - ex, bx + ex}, by2 = {by - ey, by + ey}, bz2 = {bz - ez, bz + ez};
+    const f32x2 pm = {-1.0f, 1.0f};
+    const f32x2 bx2 = __builtin_elementwise_fma((f32x2){ex, ex}, pm, (f32x2){bx, bx});
+    const f32x2 by2 = __builtin_elementwise_fma((f32x2){ey, ey}, pm, (f32x2){by, by});
+    const f32x2 bz2 = __builtin_elementwise_fma((f32x2){ez, ez}, pm, (f32x2){bz, bz});
 #endif
     const f32x2 ax2 = {ax, ax}, ay2 = {ay, ay}, az2 = {az, az};
     // entry planes are the lower ones along axes the ray travels in +, the upper ones otherwise

@@ -44,7 +44,7 @@
 // offset = 4-bit field `slot` of child_off, base = node_base for slots < n_inner, LEAF | tri_base for the others.
 struct DevNode4 { // 48 bytes, 16-byte aligned
     float org[3];      // quantisation origin (the node's box minimum)
-    uint32_t ex_off;   // byte 0..2: exponent e of axis x,y,z (plane = org + q * 2^(e-127)); byte 3: offsets of child slots 0 (low nibble) and 1
+    uint32_t ex_off;   // byte 0..2: signed exponent k of axis x,y,z (plane = org + q * 2^k, k in [-126, 127]); byte 3: offsets of child slots 0 (low nibble) and 1
     uint32_t base_off; // bits 0..23 index of the first inner child (inner children are consecutive); byte 3: offsets of child slots 2 and 3
     uint32_t tri_inf;  // bits 0..26 first triangle of the first leaf child (leaf children's triangles are consecutive, in child order); 27..29 n_inner
     uint32_t qlo[3];   // [axis]: byte i = quantised lower plane of child i (children: inner ones first, then leaves)

@@ -284,7 +284,6 @@ __global__ __launch_bounds__(WAVE, RT_SM_MIN_WAVES) void k_render_extended_sm(De
     FilterRay fray;
     fray.o = sum;
     fray.inv = sum;
-    fray.err = sum;
     Hit hit;
     hit.t = RT_F32_MAX;
     hit.prim = RT_PRIM_MISS;

@@ -194,7 +194,6 @@ __global__ __launch_bounds__(WAVE, RT_WF_MIN_WAVES) void k_wf_trace(DevScene sc,
     FilterRay fray;
     fray.o = o;
     fray.inv = o;
-    fray.err = o;
     Hit hit;
     hit.t = RT_F32_MAX;
     hit.prim = RT_PRIM_MISS;

@@ -79,9 +79,9 @@ static void check_node(Ctx& c, uint32_t node, uint32_t depth, const double plo[3
     CHECK(n_inner <= 4, "node %u: n_inner %u", node, n_inner);
     double scale[3];
     for (int a = 0; a < 3; a++) {
-        const uint32_t e = (n.ex_off >> (8 * a)) & 0xFFu;
-        CHECK(e >= 1 && e <= 254, "node %u axis %d exponent %u", node, a, e);
-        scale[a] = std::ldexp(1.0, (int)e - 127);
+        const int k = (int)(int8_t)((n.ex_off >> (8 * a)) & 0xFFu);
+        CHECK(k >= -126 && k <= 127, "node %u axis %d exponent %d", node, a, k);
+        scale[a] = std::ldexp(1.0, k);
     }
     int present = 0;
     for (int s = 0; s < 4; s++) {
