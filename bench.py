@@ -240,6 +240,11 @@ def main():
     avg_kernel_ms = float(np.mean(kernel_ms))
     achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
 
+    # PMC HBM bytes per launch were measured for the whole frame on one GPU (profiles/traffic.json); rank 0's share of a
+    # partitioned frame is scaled by its share of the segments
+    traffic = load_traffic(f"{scene.name}_{args.width}x{args.height}_{mode_name}")
+    if traffic is not None and n_gpus > 1 and total_rays > 0:
+        traffic = traffic * stc["rays"] / (total_rays / args.steps)
     if rank == 0:
         workload = f"{scene.name} {scene.n_triangles} tris {args.width}x{args.height} {spp} spp " + \
                    (f"{bounces} bounces (extended mode)" if mode_name == "extended" else
@@ -259,7 +264,7 @@ def main():
                        "segments_rank0": {"camera": stc["primary_rays"], "continuation": stc["continuation_rays"], "shadow": stc["shadow_rays"]},
                        "kernel_mrays_per_s_rank0": stc["rays"] / avg_kernel_ms / 1e3},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(f"{scene.name}_{args.width}x{args.height}_{mode_name}"),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_render_reference" if mode_name == "reference" else
                                    "wavefront pipeline (k_wf_trace<shadow> + k_wf_trace<closest> + k_wf_shade + k_wf_finish + k_wf_generate)",
                          "kernel_avg_ms": avg_kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
