@@ -60,7 +60,9 @@ def init_dist(selftest):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group(backend="gloo" if selftest else "nccl", rank=rank, world_size=world)
+        # RT_BENCH_BACKEND=gloo + RT_BENCH_DEVICE=0: rehearsal of the multi-rank path on a box with fewer GPUs than ranks
+        backend = "gloo" if selftest else os.environ.get("RT_BENCH_BACKEND", "nccl")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return dist, world, rank, local_rank
 
 
@@ -199,6 +201,7 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
+    local_rank = int(os.environ.get("RT_BENCH_DEVICE", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
