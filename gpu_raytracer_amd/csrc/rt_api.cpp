@@ -58,6 +58,7 @@ struct rt_ctx {
     std::vector<DeviceState> devs;
     std::string err;
     bool uploaded = false;
+    bool pending_dispatch = false; // rt_dispatch_tile launches are not waited for (the reference's queue.submit is not either); see sync_pending
     DevScene scene_counts{}; // counts + root_ref; pointers are per device
     rt_stats stats{};
     uint32_t frame_w = 0, frame_h = 0, frame_tile = RT_TILE_SIZE, frame_tiles_x = 0, frame_tiles_y = 0;
@@ -125,6 +126,7 @@ int upload_array(rt_ctx* ctx, T** dst, const std::vector<T>& src) {
 
 int ensure_targets(rt_ctx* ctx, DeviceState& d, uint32_t w, uint32_t h) {
     if (d.fb_w == w && d.fb_h == h && d.rgba32f) return RT_OK;
+    if (d.stream) HIPCHK(ctx, hipStreamSynchronize(d.stream)); // dispatches in flight may still write the old targets
     free_targets(d);
     HIPCHK(ctx, hipSetDevice(d.device));
     size_t n = (size_t)w * h;
@@ -193,9 +195,12 @@ DevTargets targets_for(const DeviceState& d) {
     return t;
 }
 
+int sync_pending(rt_ctx* ctx);
+
 int upload_common(rt_ctx* ctx, const rt_sphere* spheres, uint32_t n_spheres, const rt_light* lights, uint32_t n_lights,
                   const rt_vertex* vertices, uint32_t n_vertices, const std::vector<rt_triangle>& tris,
                   const std::vector<uint32_t>& prim_ids, const rt_material* materials, uint32_t n_materials) {
+    if (int rcp = sync_pending(ctx)) return rcp; // dispatches in flight still read the old scene
     if (tris.size() > RT_DEV_MAX_TRIS) return ctx->fail(RT_ERR_BAD_ARG, "too many triangles: %zu > %u", tris.size(), RT_DEV_MAX_TRIS);
     std::vector<rt::BuildTri> bt(tris.size());
     for (size_t i = 0; i < tris.size(); i++) {
@@ -354,9 +359,28 @@ uint32_t wavefront_batch(uint32_t n_blocks, uint32_t spp, uint32_t n_lights, siz
     return std::max(1u, (spp + n_batches - 1) / std::max(1u, n_batches));
 }
 
+// rt_dispatch_tile returns after the launch, like `queue.submit` in src/compute.rs:165.  Whatever needs the result or
+// the device idle (read-back, statistics, a new scene, teardown) waits here first; the kernel time reported afterwards
+// is that of the LAST dispatch.
+int sync_pending(rt_ctx* ctx) {
+    if (!ctx->pending_dispatch) return RT_OK;
+    ctx->pending_dispatch = false;
+    DeviceState& d = ctx->devs[0];
+    HIPCHK(ctx, hipSetDevice(d.device));
+    HIPCHK(ctx, hipStreamSynchronize(d.stream));
+    float ms = 0.0f;
+    HIPCHK(ctx, hipEventElapsedTime(&ms, d.ev0, d.ev1));
+    ctx->stats.kernel_ms = ms;
+    return RT_OK;
+}
+
 // Launch one frame (or one explicit tile) on every device and wait.
 int run_frame(rt_ctx* ctx, DevFrame fr, bool counters, uint32_t world, uint32_t rank, bool single_tile) {
     double w0 = now_ms();
+    if (!single_tile || counters) {
+        int rcp = sync_pending(ctx);
+        if (rcp != RT_OK) return rcp;
+    }
     size_t nd = single_tile ? 1 : ctx->devs.size();
     uint32_t total_tiles = fr.tiles_x * fr.tiles_y;
     for (size_t j = 0; j < nd; j++) {
@@ -419,6 +443,18 @@ int run_frame(rt_ctx* ctx, DevFrame fr, bool counters, uint32_t world, uint32_t 
     unsigned long long cnt[16] = {0};
     const bool extended = fr.mode == RT_MODE_EXTENDED;
     uint64_t pixels = 0;
+    if (single_tile && !counters && !extended) { // one explicit tile of the reference's dispatch sequence: do not wait
+        const uint64_t px = (uint64_t)std::min(fr.tile_w, fr.width - std::min(fr.width, fr.tile_off_x)) *
+                            std::min(fr.tile_h, fr.height - std::min(fr.height, fr.tile_off_y));
+        rt_stats& st = ctx->stats;
+        st.pixels = px;
+        st.rays = st.primary_rays = (fr.mode == RT_MODE_LEGACY || fr.cur_bounce <= fr.max_bounce) ? px : 0;
+        st.continuation_rays = st.shadow_rays = st.node_visits = st.tri_tests = 0;
+        st.kernel_ms = 0.0; // filled in by sync_pending
+        st.wall_ms = now_ms() - w0;
+        ctx->pending_dispatch = true;
+        return RT_OK;
+    }
     for (size_t j = 0; j < nd; j++) {
         DeviceState& d = ctx->devs[j];
         HIPCHK(ctx, hipSetDevice(d.device));
@@ -732,6 +768,7 @@ static int read_epilogue(rt_ctx* ctx, int which, void* out, size_t bytes) {
 
 int rt_read_rgb32f(rt_ctx* ctx, float* out, size_t n_floats) {
     if (!ctx) return RT_ERR_BAD_ARG;
+    if (int rcp = sync_pending(ctx)) return rcp;
     if (!ctx->frame_valid) return ctx->fail(RT_ERR_NOT_UPLOADED, "rt_read_rgb32f: nothing rendered yet");
     size_t n = (size_t)ctx->frame_w * ctx->frame_h;
     if (!out || n_floats != n * 3) return ctx->fail(RT_ERR_BAD_ARG, "rt_read_rgb32f: expected %zu floats, got %zu", n * 3, n_floats);
@@ -750,6 +787,7 @@ int rt_read_rgb32f(rt_ctx* ctx, float* out, size_t n_floats) {
 
 int rt_read_rgba8_channels(rt_ctx* ctx, uint8_t* red, uint8_t* green, uint8_t* blue, size_t n_bytes_each) {
     if (!ctx) return RT_ERR_BAD_ARG;
+    if (int rcp = sync_pending(ctx)) return rcp;
     if (!ctx->frame_valid) return ctx->fail(RT_ERR_NOT_UPLOADED, "rt_read_rgba8_channels: nothing rendered yet");
     size_t n = (size_t)ctx->frame_w * ctx->frame_h * 4;
     if (n_bytes_each != n) return ctx->fail(RT_ERR_BAD_ARG, "rt_read_rgba8_channels: expected %zu bytes each, got %zu", n, n_bytes_each);
@@ -765,6 +803,7 @@ int rt_read_rgba8_channels(rt_ctx* ctx, uint8_t* red, uint8_t* green, uint8_t* b
 
 int rt_read_rgba8_combined(rt_ctx* ctx, uint8_t* out, size_t n_bytes) {
     if (!ctx) return RT_ERR_BAD_ARG;
+    if (int rcp = sync_pending(ctx)) return rcp;
     if (!ctx->frame_valid) return ctx->fail(RT_ERR_NOT_UPLOADED, "rt_read_rgba8_combined: nothing rendered yet");
     size_t n = (size_t)ctx->frame_w * ctx->frame_h * 4;
     if (!out || n_bytes != n) return ctx->fail(RT_ERR_BAD_ARG, "rt_read_rgba8_combined: expected %zu bytes, got %zu", n, n_bytes);
@@ -784,6 +823,7 @@ int rt_read_rgba8_combined(rt_ctx* ctx, uint8_t* out, size_t n_bytes) {
 
 int rt_read_hits(rt_ctx* ctx, uint32_t* prim_ids, float* t, size_t n_pixels) {
     if (!ctx) return RT_ERR_BAD_ARG;
+    if (int rcp = sync_pending(ctx)) return rcp;
     if (!ctx->frame_valid) return ctx->fail(RT_ERR_NOT_UPLOADED, "rt_read_hits: nothing rendered yet");
     size_t n = (size_t)ctx->frame_w * ctx->frame_h;
     if (n_pixels != n) return ctx->fail(RT_ERR_BAD_ARG, "rt_read_hits: expected %zu pixels, got %zu", n, n_pixels);
@@ -811,6 +851,7 @@ int rt_debug_counters(rt_ctx* ctx, unsigned long long out[8]) {
 int rt_get_stats(rt_ctx* ctx, rt_stats* out) {
     if (!ctx) return RT_ERR_BAD_ARG;
     if (!out) return ctx->fail(RT_ERR_BAD_ARG, "rt_get_stats: null out");
+    if (int rcp = sync_pending(ctx)) return rcp;
     *out = ctx->stats;
     return RT_OK;
 }

@@ -20,9 +20,12 @@
  *     Nothing throws or unwinds across this boundary.
  *   - A context is single-caller (not re-entrant), as the reference's
  *     RenderState is only touched from the winit thread (src/main.rs:239-292).
- *   - rt_render / rt_dispatch_tile are synchronous: they return after the
- *     device finished, so timing is well defined (the reference never waits,
- *     src/compute.rs:165).
+ *   - rt_render is synchronous: it returns after the device finished, so timing
+ *     is well defined.  rt_dispatch_tile returns after the launch, as
+ *     queue.submit does (src/compute.rs:165: the reference never waits); the
+ *     next call that needs the result or an idle device (rt_read_*, rt_get_stats,
+ *     rt_upload_*, rt_render, rt_destroy) waits for it, and rt_get_stats then
+ *     reports the kernel time of the last dispatch.
  *   - There is no CPU fallback: without a HIP device every compute entry
  *     point fails with RT_ERR_HIP.
  */
@@ -132,7 +135,7 @@ int rt_render(rt_ctx* ctx, const rt_render_params* params);
  * the tile named by the push constants into the rgba8 texture of channel
  * pc->packed_flags & 0xFF (0..2; anything else is RT_ERR_BAD_ARG, as
  * get_compute_bind_group fails, src/renderer.rs:769-776).  Scene counts inside
- * pc->metadata_offsets are ignored in favour of the uploaded scene. */
+ * pc->metadata_offsets are ignored in favour of the uploaded scene.  Asynchronous (see above). */
 int rt_dispatch_tile(rt_ctx* ctx, const rt_push_constants* pc);
 
 /* Read back the float RGB framebuffer of the last rt_render: width*height*3 floats, row-major, y down. */
