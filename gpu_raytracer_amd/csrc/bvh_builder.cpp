@@ -1,4 +1,4 @@
-// bvh_builder.cpp — binned-SAH BVH2 build (host, multi-threaded), see bvh_builder.h.
+// bvh_builder.cpp — binned-SAH binary build (host, multi-threaded) collapsed into the 4-wide quantised layout, see bvh_builder.h.
 #include "bvh_builder.h"
 
 #include <algorithm>

@@ -341,7 +341,7 @@ __global__ __launch_bounds__(WAVE, RT_WF_MIN_WAVES) void k_wf_trace(DevScene sc,
 
 // The shading stages are bound by memory latency, not arithmetic (22 % VALU busy, 83 % of the wave time in s_waitcnt):
 // what counts is the number of DEPENDENT round trips per path.  Lights come from LDS (staged once per block), and
-// each group of per-path loads is issued together: RT_KEEP_TOGETHER pins the loaded values at one point so the
+// each group of per-path loads is issued together: RT_KEEP4 pins the loaded values at one point so the
 // compiler cannot split a record by first use and sink the later words behind a branch (each a further round trip).
 #define RT_KEEP4(v) asm volatile("" : "+v"((v).x), "+v"((v).y), "+v"((v).z), "+v"((v).w))
 __device__ __forceinline__ void stage_lights(DevLight* __restrict__ s_lights, const DevScene& sc) {
