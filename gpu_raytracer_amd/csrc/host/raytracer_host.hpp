@@ -34,7 +34,7 @@ struct RaytracerConfig {
     static constexpr uint32_t TILE_SIZE = 128;
     static constexpr uint32_t THREAD_GROUP_SIZE_X = 16, THREAD_GROUP_SIZE_Y = 16;
     static constexpr size_t DEFAULT_MAX_SPHERES = 64, DEFAULT_MAX_TRIANGLES = 64;
-    static constexpr float CAMERA_MOVE_SPEED = 0.1f, CAMERA_ROTATE_SENSITIVITY = 0.005f;
+    static constexpr float CAMERA_MOVE_SPEED = 0.1f, CAMERA_ROTATE_SENSITIVITY = 0.005f, CAMERA_PITCH_CLAMP = 0.99f;
     static constexpr float MIN_RAY_DISTANCE = 0.00001f;
     static constexpr uint32_t MAX_PUSH_CONSTANT_SIZE = 128;
 };
@@ -56,6 +56,35 @@ using PushConstants = rt_push_constants;
 namespace camera {
 inline Camera new_() { return Camera{{0.0f, 0.0f, 5.0f}, {0.0f, 0.0f, -1.0f}, {0.0f, 1.0f, 0.0f}, 45.0f}; } // :231-238
 } // namespace camera
+
+// CameraController — src/input.rs:46-97: the arithmetic behind mouse-drag rotation and key movement (the event plumbing
+// of InputState is window-system code and stays out).  Used for scripted fly-throughs: the same camera path as the
+// interactive application would produce from the same deltas.
+namespace camera_controller {
+// mouse delta in pixels -> yaw about +Y, then the y component pushed by the vertical delta and clamped, then normalised
+inline void rotate_camera(Camera& cam, double delta_x, double delta_y) { // :49-76
+    const float yaw = (float)delta_x * RaytracerConfig::CAMERA_ROTATE_SENSITIVITY;
+    const float pitch = (float)delta_y * RaytracerConfig::CAMERA_ROTATE_SENSITIVITY;
+    const float c = std::cos(yaw), s = std::sin(yaw);
+    const float x = cam.direction[0], z = cam.direction[2];
+    cam.direction[0] = x * c - z * s;
+    cam.direction[2] = x * s + z * c;
+    const float y = cam.direction[1] - pitch;
+    cam.direction[1] = std::max(-RaytracerConfig::CAMERA_PITCH_CLAMP, std::min(RaytracerConfig::CAMERA_PITCH_CLAMP, y));
+    const float len = std::sqrt(cam.direction[0] * cam.direction[0] + cam.direction[1] * cam.direction[1] + cam.direction[2] * cam.direction[2]);
+    if (len > 0.0f)
+        for (float& v : cam.direction) v /= len;
+}
+// forward / right in units of CAMERA_MOVE_SPEED; "right" is direction x up (not normalised, as in the reference)
+inline void move_camera(Camera& cam, float forward, float right) { // :79-97
+    const float speed = RaytracerConfig::CAMERA_MOVE_SPEED;
+    for (int a = 0; a < 3; a++) cam.position[a] += cam.direction[a] * forward * speed;
+    const float* d = cam.direction;
+    const float* u = cam.up;
+    const float side[3] = {d[1] * u[2] - d[2] * u[1], d[2] * u[0] - d[0] * u[2], d[0] * u[1] - d[1] * u[0]};
+    for (int a = 0; a < 3; a++) cam.position[a] += side[a] * right * speed;
+}
+} // namespace camera_controller
 
 namespace material {
 inline uint16_t f32_to_f16_u16(float v) { return rt::f32_to_f16_bits(v); } // :250-252 (half::f16::from_f32, RNE)

@@ -42,6 +42,13 @@ void rt_host_push_constants_new(rt_push_constants* out, const float resolution[2
                                              triangles_per_buffer, *offsets, color_channel, current_bounce, max_bounce, frame_seed);
 }
 
+void rt_host_camera_rotate(rt_camera* camera, double delta_x, double delta_y) {
+    if (camera) raytracer::camera_controller::rotate_camera(*camera, delta_x, delta_y);
+}
+void rt_host_camera_move(rt_camera* camera, float forward, float right) {
+    if (camera) raytracer::camera_controller::move_camera(*camera, forward, right);
+}
+
 void rt_host_tile_count(uint32_t width, uint32_t height, uint32_t tile_size, uint32_t* tiles_x, uint32_t* tiles_y) {
     TileHelper::calculate_tile_count(width, height, tile_size, tiles_x, tiles_y);
 }

@@ -122,6 +122,27 @@ def render_progressive(ctx, scene, width, height, camera=None):
 
 
 # ---- row N1: glTF loading -----------------------------------------------------------------------------
+HOST_SYMBOLS += ["rt_host_camera_rotate", "rt_host_camera_move"]
+
+
+def camera_rotate(camera, delta_x, delta_y):
+    """CameraController::rotate_camera (src/input.rs:49-76) on a copy of `camera`."""
+    cam = np.array(camera, dtype=T.CAMERA).copy()
+    lib = _lib()
+    lib.rt_host_camera_rotate.restype = None
+    lib.rt_host_camera_rotate(_p(cam), C.c_double(delta_x), C.c_double(delta_y))
+    return cam
+
+
+def camera_move(camera, forward, right):
+    """CameraController::move_camera (src/input.rs:79-97) on a copy of `camera`."""
+    cam = np.array(camera, dtype=T.CAMERA).copy()
+    lib = _lib()
+    lib.rt_host_camera_move.restype = None
+    lib.rt_host_camera_move(_p(cam), C.c_float(forward), C.c_float(right))
+    return cam
+
+
 HOST_SYMBOLS += ["rt_host_gltf_load", "rt_host_gltf_load_glb", "rt_host_scene_counts", "rt_host_scene_copy", "rt_host_scene_free",
                  "rt_host_write_ppm", "rt_host_write_png", "rt_host_progressive_timing"]
 GLTF_ERRORS = {-11: "IoError", -12: "GltfError", -13: "ValidationError"}

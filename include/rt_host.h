@@ -25,6 +25,11 @@ void rt_host_push_constants_new(rt_push_constants* out, const float resolution[2
                                 const uint32_t total_tiles[2], uint32_t triangles_per_buffer, const rt_scene_metadata_offsets* offsets,
                                 uint32_t color_channel, uint32_t wavefront_mode, uint32_t current_bounce, uint32_t max_bounce,
                                 uint32_t frame_seed);
+/* CameraController::rotate_camera / move_camera (src/input.rs:49-97): mouse delta in pixels, movement in units of
+ * CAMERA_MOVE_SPEED.  For scripted fly-throughs. */
+void rt_host_camera_rotate(rt_camera* camera, double delta_x, double delta_y);
+void rt_host_camera_move(rt_camera* camera, float forward, float right);
+
 /* TileHelper::calculate_tile_count / calculate_tiles_per_frame (shared/src/lib.rs:1187-1203) */
 void rt_host_tile_count(uint32_t width, uint32_t height, uint32_t tile_size, uint32_t* tiles_x, uint32_t* tiles_y);
 uint32_t rt_host_tiles_per_frame(uint32_t total_tiles);

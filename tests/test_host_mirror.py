@@ -159,3 +159,30 @@ def test_reference_frame_loop_on_gpu(gpu_ctx, oracle_mod):
     comb = gpu_ctx.read_rgba8_combined()
     ref = oracle_mod.render_frame(oracle_mod.PackedScene(scene), w, h, want_rgba8=True)
     np.testing.assert_array_equal(comb, ref["combined"])
+
+
+def test_camera_controller_maths():
+    """CameraController::rotate_camera / move_camera (src/input.rs:49-97): yaw about +Y by 0.005 rad per pixel, the y
+    component shifted by the vertical delta and clamped to +-0.99, then normalised; movement along the view direction and
+    along direction x up in steps of 0.1."""
+    cam = H.camera()  # position (0,0,5), direction (0,0,-1), up (0,1,0)
+    same = host.camera_rotate(cam, 0.0, 0.0)
+    np.testing.assert_array_equal(same["direction"], cam["direction"])
+    r = host.camera_rotate(cam, 100.0, 0.0)  # yaw 0.5 rad: x' = -z sin = sin(0.5), z' = z cos = -cos(0.5)
+    np.testing.assert_allclose(r["direction"], [np.sin(0.5), 0.0, -np.cos(0.5)], rtol=0, atol=2e-7)
+    r = host.camera_rotate(cam, 0.0, -40.0)  # y = 0 + 0.2, then normalise
+    n = np.sqrt(1.0 + 0.04)
+    np.testing.assert_allclose(r["direction"], [0.0, 0.2 / n, -1.0 / n], rtol=0, atol=2e-7)
+    r = host.camera_rotate(cam, 0.0, -1000.0)  # clamped to 0.99 before the normalisation
+    n = np.sqrt(1.0 + 0.99 ** 2)
+    np.testing.assert_allclose(r["direction"], [0.0, 0.99 / n, -1.0 / n], rtol=0, atol=2e-7)
+    np.testing.assert_array_equal(r["position"], cam["position"])
+    m = host.camera_move(cam, 3.0, 0.0)
+    np.testing.assert_allclose(m["position"], [0.0, 0.0, 5.0 - 0.3], rtol=0, atol=1e-6)
+    m = host.camera_move(cam, 0.0, 2.0)  # direction x up = (0,0,-1) x (0,1,0) = (1,0,0)
+    np.testing.assert_allclose(m["position"], [0.2, 0.0, 5.0], rtol=0, atol=1e-6)
+    # a scripted fly-through keeps the direction normalised and the position finite
+    c = cam
+    for k in range(200):
+        c = host.camera_move(host.camera_rotate(c, 7.0, (-1) ** k * 3.0), 1.0, 0.25)
+    assert abs(np.linalg.norm(c["direction"]) - 1.0) < 1e-5 and np.isfinite(c["position"]).all()
