@@ -34,17 +34,19 @@ static double now_ms() {
 
 static int usage(const char* argv0, int rc) {
     std::fprintf(rc ? stderr : stdout,
-                 "usage: %s [--gltf FILE.gltf|.glb] [--size WxH] [--out FILE.png|.ppm] [--spp N --bounces B] [--device D]\n"
+                 "usage: %s [--gltf FILE.gltf|.glb] [--size WxH] [--out FILE.png|.ppm] [--spp N --bounces B] [--fly FRAMES] [--device D]\n"
                  "  without --gltf the reference's default scene (6 spheres, 2 triangles, 1 light) is rendered;\n"
                  "  without --spp the reference path runs: progressive 128x128 tiles, three channel dispatches per tile;\n"
-                 "  with --spp N the extended mode (jittered samples, shadow rays, --bounces B, default 4) runs through rt_render.\n",
+                 "  with --spp N the extended mode (jittered samples, shadow rays, --bounces B, default 4) runs through rt_render;\n"
+                 "  with --fly FRAMES a scripted fly-through (CameraController deltas of src/input.rs) renders FRAMES whole frames with\n"
+                 "  the reference semantics, reads each back and reports frames per second; the last frame is written.\n",
                  argv0);
     return rc;
 }
 
 int main(int argc, char** argv) {
     std::string gltf, out = "out.png";
-    uint32_t width = 800, height = 600, spp = 0, bounces = 4;
+    uint32_t width = 800, height = 600, spp = 0, bounces = 4, fly = 0;
     int device = 0;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
@@ -58,6 +60,7 @@ int main(int argc, char** argv) {
             if (std::sscanf(v, "%ux%u", &width, &height) != 2 || !width || !height) return usage(argv[0], 2);
         } else if (a == "--spp") spp = (uint32_t)std::atoi(v);
         else if (a == "--bounces") bounces = (uint32_t)std::atoi(v);
+        else if (a == "--fly") fly = (uint32_t)std::atoi(v);
         else if (a == "--device") device = std::atoi(v);
         else return usage(argv[0], 2);
     }
@@ -88,7 +91,36 @@ int main(int argc, char** argv) {
     BufferManager buffers;
     std::vector<uint8_t> rgba8((size_t)width * height * 4);
 
-    if (spp == 0) {
+    if (fly > 0) {
+        // ---- scripted fly-through: what dragging the mouse and holding W/D does in the reference (src/main.rs:150-186 ->
+        // CameraController), one whole frame per step through rt_render (all tiles, three channels in one pass) + read-back ----
+        rc = buffers.update(ctx, scene, nullptr);
+        if (rc != RT_OK) return fail("BufferManager::update", rc);
+        rt_render_params p;
+        std::memset(&p, 0, sizeof p);
+        p.width = width;
+        p.height = height;
+        p.spp = 1;
+        p.mode = RT_MODE_LEGACY;
+        p.tile_world = 1;
+        double device_ms = 0.0;
+        const double t0 = now_ms();
+        for (uint32_t f = 0; f < fly; f++) {
+            camera_controller::rotate_camera(scene.camera, (f / 60) % 2 ? -1.0 : 1.0, (f / 30) % 2 ? 0.5 : -0.5); // sweeps left and right, nods
+            camera_controller::move_camera(scene.camera, 0.05f, (f / 60) % 2 ? 0.05f : -0.05f);                  // creeps forward, strafes
+            p.camera = scene.camera;
+            rc = rt_render(ctx, &p);
+            if (rc != RT_OK) return fail("rt_render", rc);
+            rt_stats st;
+            rt_get_stats(ctx, &st);
+            device_ms += st.kernel_ms;
+            rc = rt_read_rgba8_combined(ctx, rgba8.data(), rgba8.size());
+            if (rc != RT_OK) return fail("rt_read_rgba8_combined", rc);
+        }
+        const double total = now_ms() - t0;
+        std::printf("fly-through: %u frames of %ux%u in %.1f ms = %.0f frames/s including the read-back (%.3f ms of device time per frame)\n", fly, width, height,
+                    total, fly / (total * 1e-3), device_ms / fly);
+    } else if (spp == 0) {
         // ---- the reference's progressive loop (src/main.rs:278-279 -> compute.rs:12) ----
         ProgressiveState progressive;
         progressive.resize(width, height);

@@ -192,6 +192,15 @@ def test_native_front_end_renders_the_gltf_fixture_like_the_oracle(oracle_mod, t
     scene = host.load_gltf(os.path.join(GOLD, "cornell12.gltf"))
     ref = oracle_mod.render_frame(oracle_mod.PackedScene(scene, use_bvh=False), w, h)
     np.testing.assert_array_equal(img, ref["combined"][..., :3])
+    fly = subprocess.run([exe, "--fly", "5", "--size", "160x120", "--out", str(tmp_path / "fly.ppm")], capture_output=True, text=True)
+    assert fly.returncode == 0 and "fly-through: 5 frames of 160x120" in fly.stdout, fly.stderr
+    # the same five camera steps through the Python mirror: identical last frame
+    cam = scenes.default_scene().camera
+    for f in range(5):
+        cam = host.camera_move(host.camera_rotate(cam, 1.0, -0.5), 0.05, -0.05)
+    ref5 = oracle_mod.render_frame(oracle_mod.PackedScene(scenes.default_scene(), use_bvh=False), 160, 120, camera=cam)
+    raw5 = (tmp_path / "fly.ppm").read_bytes()
+    np.testing.assert_array_equal(np.frombuffer(raw5[len(b"P6\n160 120\n255\n"):], np.uint8).reshape(120, 160, 3), ref5["combined"][..., :3])
     ppm2 = tmp_path / "ext.ppm"
     out = subprocess.run([exe, "--size", "160x120", "--spp", "4", "--bounces", "2", "--out", str(ppm2)], capture_output=True, text=True)
     assert out.returncode == 0 and "extended mode: 4 spp, 2 bounces" in out.stdout, out.stderr
