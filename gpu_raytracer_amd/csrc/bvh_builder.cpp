@@ -9,6 +9,7 @@
 #include <limits>
 #include <numeric>
 #include <thread>
+#include <utility>
 
 namespace rt {
 namespace {
@@ -46,6 +47,18 @@ struct TmpNode {
     uint32_t start, count;
 };
 
+#ifndef RT_BVH_REINSERT
+#define RT_BVH_REINSERT 1
+#endif
+#ifndef RT_BVH_REINSERT_PASSES
+#define RT_BVH_REINSERT_PASSES 2
+#endif
+#ifndef RT_BVH_REINSERT_MAX
+#define RT_BVH_REINSERT_MAX 150000
+#endif
+#ifndef RT_BVH_REINSERT_FRACTION
+#define RT_BVH_REINSERT_FRACTION 0.25
+#endif
 #ifndef RT_BVH_BINS
 #define RT_BVH_BINS 32 /* SAH bins per axis: 32 instead of 16 gives 3 % fewer node visits on the sponza-like scene (+2 % throughput), 48 / 64 no more */
 #endif
@@ -200,6 +213,121 @@ struct Builder {
     }
 };
 
+#if RT_BVH_REINSERT
+// Insertion-based optimisation of the binary tree (after Bittner, Hapala, Havran, "Fast Insertion-Based Optimization of
+// Bounding Volume Hierarchies", 2013, in its simplest form): take a subtree out (its parent goes with it, the sibling moves
+// up), find by branch and bound the node next to which it enlarges the ancestors' boxes least, and put it back there.
+// Candidates are the nodes with the largest area first.  The sum of the inner nodes' areas - what a top-down SAH build
+// only approximates greedily - can only go down.  Returns the depth of the resulting tree.
+static float union_area(const Box& a, const Box& b) {
+    Box u = a;
+    u.grow(b);
+    return u.half_area();
+}
+static uint32_t reinsertion_optimize(std::vector<TmpNode>& nodes, uint32_t n_nodes, uint32_t& root, int passes, double fraction) {
+    std::vector<uint32_t> parent(n_nodes, 0xFFFFFFFFu);
+    auto is_leaf = [&](uint32_t x) { return nodes[x].left == 0xFFFFFFFFu; };
+    {
+        std::vector<uint32_t> st{root};
+        while (!st.empty()) {
+            const uint32_t x = st.back();
+            st.pop_back();
+            if (is_leaf(x)) continue;
+            parent[nodes[x].left] = parent[nodes[x].right] = x;
+            st.push_back(nodes[x].left);
+            st.push_back(nodes[x].right);
+        }
+    }
+    auto refit_up = [&](uint32_t x) { // recompute boxes from x to the root
+        while (x != 0xFFFFFFFFu) {
+            Box bx = nodes[nodes[x].left].box;
+            bx.grow(nodes[nodes[x].right].box);
+            nodes[x].box = bx;
+            x = parent[x];
+        }
+    };
+    struct Entry {
+        float induced;
+        uint32_t node;
+        bool operator<(const Entry& o) const { return induced > o.induced; } // min-heap on the induced cost
+    };
+    for (int pass = 0; pass < passes; pass++) {
+        std::vector<uint32_t> cand;
+        for (uint32_t x = 0; x < n_nodes; x++)
+            if (x != root && parent[x] != 0xFFFFFFFFu && parent[x] != root) cand.push_back(x);
+        // a bounded number of candidates per pass (the step is serial: ~1.4 us per candidate): the largest nodes matter most
+        const size_t take = std::min({cand.size(), (size_t)std::max(1.0, fraction * (double)cand.size()), (size_t)RT_BVH_REINSERT_MAX});
+        std::partial_sort(cand.begin(), cand.begin() + (long)take, cand.end(), [&](uint32_t a, uint32_t b) {
+            const float aa = nodes[a].box.half_area(), ab = nodes[b].box.half_area();
+            return aa > ab || (aa == ab && a < b);
+        });
+        cand.resize(take);
+        std::vector<Entry> heap;
+        for (uint32_t nd : cand) {
+            const uint32_t p = parent[nd];
+            if (p == 0xFFFFFFFFu || p == root) continue; // moved under the root by an earlier step
+            const uint32_t g = parent[p];
+            const uint32_t sib = nodes[p].left == nd ? nodes[p].right : nodes[p].left;
+            // take nd (and p) out: the sibling takes p's place
+            if (nodes[g].left == p) nodes[g].left = sib;
+            else nodes[g].right = sib;
+            parent[sib] = g;
+            refit_up(g);
+            // branch and bound for the best neighbour
+            const Box& nb = nodes[nd].box;
+            const float na = nb.half_area();
+            float best_cost = std::numeric_limits<float>::infinity();
+            uint32_t best = sib;
+            heap.clear();
+            heap.push_back({0.0f, root});
+            while (!heap.empty()) {
+                std::pop_heap(heap.begin(), heap.end());
+                const Entry e = heap.back();
+                heap.pop_back();
+                if (e.induced + na >= best_cost) break; // nothing cheaper can follow (heap order)
+                const float direct = union_area(nodes[e.node].box, nb);
+                const float total = e.induced + direct;
+                if (total < best_cost) {
+                    best_cost = total;
+                    best = e.node;
+                }
+                if (!is_leaf(e.node)) {
+                    const float child_induced = total - nodes[e.node].box.half_area();
+                    if (child_induced + na < best_cost) {
+                        heap.push_back({child_induced, nodes[e.node].left});
+                        std::push_heap(heap.begin(), heap.end());
+                        heap.push_back({child_induced, nodes[e.node].right});
+                        std::push_heap(heap.begin(), heap.end());
+                    }
+                }
+            }
+            // put it back: p becomes the parent of (best, nd) where best was
+            const uint32_t bp = parent[best];
+            nodes[p].left = best;
+            nodes[p].right = nd;
+            parent[best] = p;
+            parent[nd] = p;
+            parent[p] = bp;
+            if (bp == 0xFFFFFFFFu) root = p;
+            else if (nodes[bp].left == best) nodes[bp].left = p;
+            else nodes[bp].right = p;
+            refit_up(p);
+        }
+    }
+    uint32_t depth = 0; // inner levels on the longest path
+    std::vector<std::pair<uint32_t, uint32_t>> st{{root, 1u}};
+    while (!st.empty()) {
+        auto [x, d] = st.back();
+        st.pop_back();
+        if (is_leaf(x)) continue;
+        depth = std::max(depth, d);
+        st.push_back({nodes[x].left, d + 1});
+        st.push_back({nodes[x].right, d + 1});
+    }
+    return depth;
+}
+#endif
+
 void put_tri(const BuildTri& t, DevTri* o) {
     for (int a = 0; a < 3; a++) {
         o->v0[a] = t.v0[a];
@@ -245,6 +373,17 @@ void build_bvh(const BuildTri* tris_in, size_t n_in, const BvhBuildOptions& opt_
     b.nodes.resize(2 * n);
     uint32_t root = b.alloc();
     b.build(root, 0, (uint32_t)n, 0);
+#if RT_BVH_REINSERT
+    if (n > 8) { // keep the top-down tree when the optimised one would exceed the depth the kernels' stacks are sized for
+        std::vector<TmpNode> keep(b.nodes.begin(), b.nodes.begin() + b.next_node.load());
+        const uint32_t keep_root = root;
+        const uint32_t d = reinsertion_optimize(b.nodes, b.next_node.load(), root, RT_BVH_REINSERT_PASSES, RT_BVH_REINSERT_FRACTION);
+        if (d > b.opt.max_depth) {
+            std::copy(keep.begin(), keep.end(), b.nodes.begin());
+            root = keep_root;
+        }
+    }
+#endif
 
     // ---- collapse to a 4-wide tree and emit it in the quantised layout ----
     out.tris.resize(n);
