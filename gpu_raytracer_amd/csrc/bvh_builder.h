@@ -37,7 +37,7 @@ struct BvhBuildOptions {
     int threads = 0;        // 0 = hardware_concurrency
     uint32_t max_leaf = 4;  // <= RT_DEV_MAX_LEAF_TRIS
     uint32_t max_depth = RT_DEV_MAX_BVH_DEPTH;
-    float cost_traverse = 1.0f;
+    float cost_traverse = 0.7f; // relative to cost_intersect: measured optimum on the headline frame (0.5-0.75: +1 % over 1.0)
     float cost_intersect = 1.0f;
 };
 
