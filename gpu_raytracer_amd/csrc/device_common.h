@@ -423,14 +423,14 @@ __device__ __forceinline__ V3 calculate_lighting(const DevScene& sc, const DevMa
 }
 
 // hit -> (point, geometric normal, material id)
-__device__ __forceinline__ void hit_geometry(const DevScene& sc, const Hit& hit, V3 o, V3 d, V3& point, V3& normal, uint32_t& material_id) {
-    point = o + d * hit.t; // Ray::at, ray.rs:56-58
-    if (hit.prim & RT_PRIM_SPHERE_FLAG) {
-        const DevSphere& s = sc.spheres[hit.slot];
+// geometric normal and material at a hit point: `sphere` selects DevScene::spheres[slot], else DevScene::tris[slot]
+__device__ __forceinline__ void surface_at(const DevScene& sc, bool sphere, uint32_t slot, V3 point, V3& normal, uint32_t& material_id) {
+    if (sphere) {
+        const DevSphere& s = sc.spheres[slot];
         normal = normalize(point - ld3(s.center)); // intersection.rs:80
         material_id = s.material_id;
     } else {
-        const float4* p = reinterpret_cast<const float4*>(sc.tris + hit.slot);
+        const float4* p = reinterpret_cast<const float4*>(sc.tris + slot);
         float4 q0 = p[0], q1 = p[1], q2 = p[2];
         asm volatile("" : "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w), "+v"(q2.x), "+v"(q2.y)); // one round trip for the record
         V3 e1 = v3(q0.w, q1.x, q1.y);
@@ -438,6 +438,10 @@ __device__ __forceinline__ void hit_geometry(const DevScene& sc, const Hit& hit,
         normal = normalize(cross(e1, e2)); // geometric, winding dependent, never flipped (intersection.rs:132)
         material_id = __float_as_uint(q2.y);
     }
+}
+__device__ __forceinline__ void hit_geometry(const DevScene& sc, const Hit& hit, V3 o, V3 d, V3& point, V3& normal, uint32_t& material_id) {
+    point = o + d * hit.t; // Ray::at, ray.rs:56-58
+    surface_at(sc, (hit.prim & RT_PRIM_SPHERE_FLAG) != 0, hit.slot, point, normal, material_id);
 }
 
 // The transmission mix of calculate_shading (lib.rs:323-337) for all three channel passes at once.

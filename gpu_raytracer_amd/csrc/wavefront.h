@@ -33,7 +33,7 @@ struct WfBuffers {
     // per path slot (P = samples_in_batch * n_blocks * 64)
     float4* ray_o;       // xyz origin
     float4* ray_d;       // xyz direction (also the incoming direction of the current vertex)
-    uint4* hit;          // x = t bits, y = primitive id, z = triangle slot / sphere index
+    uint4* hit;          // xyz = hit point bits, w = RT_PRIM_MISS | RT_PRIM_SPHERE_FLAG + sphere index | triangle slot
     float4* thr;         // xyz throughput, w = bits: hero channel | depth << 8
     float4* rad;         // xyz radiance of the sample so far, w = bits: rng state
     float4* vtx_p;       // xyz vertex position, w = bits: material id

@@ -311,7 +311,11 @@ __global__ __launch_bounds__(WAVE, RT_WF_MIN_WAVES) void k_wf_trace(DevScene sc,
                 if (ANY) {
                     if (hit.prim == RT_PRIM_MISS) atomicOr(&wb.vis[id], 1u << li);
                 } else {
-                    wb.hit[id] = make_uint4(__float_as_uint(hit.t), hit.prim, hit.slot, 0u);
+                    // the hit POINT (Ray::at, ray.rs:56-58: o + d * t) and what was hit: k_wf_shade then needs neither the
+                    // ray nor t (32 bytes less to read per vertex)
+                    const V3 hp = o + d * hit.t;
+                    const uint32_t code = hit.prim == RT_PRIM_MISS ? RT_PRIM_MISS : ((hit.prim & RT_PRIM_SPHERE_FLAG) ? hit.prim : hit.slot);
+                    wb.hit[id] = make_uint4(__float_as_uint(hp.x), __float_as_uint(hp.y), __float_as_uint(hp.z), code);
                 }
                 active = false;
             }
@@ -395,20 +399,14 @@ __global__ __launch_bounds__(256, RT_WF_SHADE_WAVES) void k_wf_shade(DevScene sc
         DevMaterial m = {};
         if (have) {
             uint4 h = wb.hit[id];
-            float4 ro = wb.ray_o[id], rd = wb.ray_d[id];
-            asm volatile("" : "+v"(h.x), "+v"(h.y), "+v"(h.z));
-            RT_KEEP4(ro);
-            RT_KEEP4(rd);
+            asm volatile("" : "+v"(h.x), "+v"(h.y), "+v"(h.z), "+v"(h.w));
             // throughput / radiance are only read where a path ends here (a quarter of this stage's read traffic otherwise)
-            if (h.y == RT_PRIM_MISS) { // process_wavefront_ray, wavefront.rs:146-151
+            if (h.w == RT_PRIM_MISS) { // process_wavefront_ray, wavefront.rs:146-151
                 const V3 radiance = f4v(wb.rad[id]) + v3(0.1f, 0.2f, 0.3f) * f4v(wb.thr[id]);
                 wf_end_path(wb, id, radiance);
             } else {
-                Hit hit;
-                hit.t = __uint_as_float(h.x);
-                hit.prim = h.y;
-                hit.slot = h.z;
-                hit_geometry(sc, hit, f4v(ro), f4v(rd), point, normal, material_id);
+                point = v3(__uint_as_float(h.x), __uint_as_float(h.y), __uint_as_float(h.z));
+                surface_at(sc, (h.w & RT_PRIM_SPHERE_FLAG) != 0, h.w & ~RT_PRIM_SPHERE_FLAG, point, normal, material_id);
                 if (material_id >= sc.n_materials) {
                     const V3 radiance = f4v(wb.rad[id]) + v3(1.0f, 0.0f, 1.0f) * f4v(wb.thr[id]);
                     wf_end_path(wb, id, radiance);
