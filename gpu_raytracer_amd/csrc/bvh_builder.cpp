@@ -587,6 +587,10 @@ void build_bvh(const BuildTri* tris_in, size_t n_in, const BvhBuildOptions& opt_
                     hi = std::min(std::max(hi, 0.0), 255.0);
                     while (lo > 0.0 && (double)d.org[a] + lo * scale > (double)cb.mn[a]) lo -= 1.0;
                     while (hi < 255.0 && (double)d.org[a] + hi * scale < (double)cb.mx[a]) hi += 1.0;
+#ifdef RT_BVH_EXTRA_INFLATE /* measurement only: what does one more grid step of inflation per side cost? */
+                    lo = std::max(lo - RT_BVH_EXTRA_INFLATE, 0.0);
+                    hi = std::min(hi + RT_BVH_EXTRA_INFLATE, 255.0);
+#endif
                     qlo = (uint32_t)lo;
                     qhi = (uint32_t)hi;
                 }
