@@ -179,9 +179,10 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     n_gpus = max(world, 1)
-    # the reference's 128x128 tiles on one GPU; 32x32 when the frame is dealt over several (finer tiles so that
-    # every rank gets hundreds of them; measured per-rank imbalance at 8 ranks 2.0 % -> 0.6 %).  The image does not depend on it.
-    tile = 128 if n_gpus == 1 else 32
+    # 32x32 tiles (finer tiles so that every rank gets hundreds of them; measured per-rank imbalance at 8 ranks
+    # 2.0 % -> 0.6 %).  On one GPU the tile size only orders the work; 16..64-pixel tiles measured 2 % faster than the
+    # reference's 128 at 1080p (scripts/tile_size_probe.py).  The image does not depend on it (bit-identical for 8..256).
+    tile = 32
 
     if args.selftest_cpu:
         tiles, tx, ty = owned_tiles(args.width, args.height, tile, rank, n_gpus)
