@@ -309,7 +309,6 @@ int ensure_wavefront(rt_ctx* ctx, DeviceState& d, uint32_t n_blocks, uint32_t ba
     HIPCHK(ctx, alloc((void**)&w.vtx_p, P * 16));
     HIPCHK(ctx, alloc((void**)&w.vtx_n, P * 16));
     HIPCHK(ctx, alloc((void**)&w.sample_rad, P * 16));
-    HIPCHK(ctx, alloc((void**)&w.vis, P * 4));
     HIPCHK(ctx, alloc((void**)&w.pxy, P * 4));
     // producers reserve queue space in windows (wavefront.hip): wf_queue_slots is the bound on real entries + padding
     const uint32_t lights = std::max(1u, n_lights);
@@ -351,7 +350,7 @@ uint32_t wavefront_batch(uint32_t n_blocks, uint32_t spp, uint32_t n_lights, siz
     uint64_t target_paths = 64ull << 20;
     if (const char* e = std::getenv("RT_WF_TARGET_PATHS")) target_paths = std::max<uint64_t>(1, std::strtoull(e, nullptr, 10));
     const uint64_t lights = std::max(1u, n_lights);
-    const uint64_t bytes_per_path = 8 * 16 + 4 + 4 + 2 * 10 + 10 * lights; // path state, vis, pxy, two extension queues, shadow queue (2.5 slots per entry)
+    const uint64_t bytes_per_path = 8 * 16 + 4 + 2 * 10 + 10 * lights; // path state, vis, pxy, two extension queues, shadow queue (2.5 slots per entry)
     target_paths = std::min<uint64_t>(target_paths, free_bytes / 2 / bytes_per_path);
     target_paths = std::min<uint64_t>(target_paths, wavefront_max_paths(n_lights));
     const uint32_t max_batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(spp, target_paths / per_sample));

@@ -37,9 +37,8 @@ struct WfBuffers {
     float4* thr;         // xyz throughput, w = bits: hero channel | depth << 8
     float4* rad;         // xyz radiance of the sample so far, w = bits: rng state
     float4* vtx_p;       // xyz vertex position, w = bits: material id
-    float4* vtx_n;       // xyz geometric normal
+    float4* vtx_n;       // xyz geometric normal, w = bits: light li is visible from the current vertex (set by the shadow stage)
     float4* sample_rad;  // xyz final radiance of the sample (written when the path ends)
-    uint32_t* vis;       // bit li set: light li is visible from the current vertex
     uint32_t* pxy;       // x | y << 16, 0xFFFFFFFF = no pixel (tile edge)
     // queues
     uint32_t* q_ext[2];  // path ids to extend (double buffered)

@@ -309,7 +309,7 @@ __global__ __launch_bounds__(WAVE, RT_WF_MIN_WAVES) void k_wf_trace(DevScene sc,
             }
             if (active && cur == WF_REF_NONE && pleaf == WF_REF_NONE) { // segment finished
                 if (ANY) {
-                    if (hit.prim == RT_PRIM_MISS) atomicOr(&wb.vis[id], 1u << li);
+                    if (hit.prim == RT_PRIM_MISS) atomicOr(reinterpret_cast<uint32_t*>(&wb.vtx_n[id]) + 3, 1u << li); // visibility bits live in vtx_n.w
                 } else {
                     // the hit POINT (Ray::at, ray.rs:56-58: o + d * t) and what was hit: k_wf_shade then needs neither the
                     // ray nor t (32 bytes less to read per vertex)
@@ -415,7 +415,6 @@ __global__ __launch_bounds__(256, RT_WF_SHADE_WAVES) void k_wf_shade(DevScene sc
                     m = load_material(sc, material_id);
                     wb.vtx_p[id] = make_float4(point.x, point.y, point.z, __uint_as_float(material_id));
                     wb.vtx_n[id] = make_float4(normal.x, normal.y, normal.z, 0.0f);
-                    wb.vis[id] = 0u;
                 }
             }
         }
@@ -490,21 +489,19 @@ __global__ __launch_bounds__(256, RT_WF_SHADE_WAVES) void k_wf_finish(DevScene s
         id_next = i_next < count ? queue[i_next] : WF_SENTINEL;
         float4 vp = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
         float4 vn = vp, th = vp, ra = vp, rdin = vp;
-        uint32_t vis = 0;
         if (id != WF_SENTINEL) { // the whole path record in one round trip
             vp = wb.vtx_p[id];
             vn = wb.vtx_n[id];
             th = wb.thr[id];
             ra = wb.rad[id];
             rdin = wb.ray_d[id];
-            vis = wb.vis[id];
             RT_KEEP4(vp);
             RT_KEEP4(vn);
             RT_KEEP4(th);
             RT_KEEP4(ra);
             RT_KEEP4(rdin);
-            asm volatile("" : "+v"(vis));
         }
+        const uint32_t vis = __float_as_uint(vn.w); // one bit per light, set by the shadow stage
         if (__float_as_uint(vp.w) != 0xFFFFFFFFu) { // paths that ended in k_wf_shade carry the "no vertex" marker
             const V3 point = f4v(vp), normal = f4v(vn);
             const uint32_t material_id = __float_as_uint(vp.w);
