@@ -6,7 +6,7 @@ sp = scenes.sponza_like()
 with api.Context() as ctx:
     ctx.upload_scene(sp)
     for w, h in ((1920, 1080),):
-        for ts in (128, 120, 64, 40, 24):
+        for ts in (128, 64):
             best = 1e9
             for rep in range(3):
                 st = ctx.render(w, h, sp.camera, mode=2, spp=64, max_bounces=4, tile_size=ts)
