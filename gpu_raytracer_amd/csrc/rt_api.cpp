@@ -134,11 +134,12 @@ int ensure_targets(rt_ctx* ctx, DeviceState& d, uint32_t w, uint32_t h) {
     for (int c = 0; c < 3; c++) HIPCHK(ctx, hipMalloc((void**)&d.chan[c], n * 4));
     HIPCHK(ctx, hipMalloc((void**)&d.prim_id, n * 4));
     HIPCHK(ctx, hipMalloc((void**)&d.hit_t, n * 4));
-    // fresh textures read as zero, like newly created wgpu textures
-    HIPCHK(ctx, hipMemset(d.rgba32f, 0, n * 16));
-    for (int c = 0; c < 3; c++) HIPCHK(ctx, hipMemset(d.chan[c], 0, n * 4));
-    HIPCHK(ctx, hipMemset(d.prim_id, 0xFF, n * 4));
-    HIPCHK(ctx, hipMemset(d.hit_t, 0, n * 4));
+    // fresh textures read as zero, like newly created wgpu textures.  On d.stream: it is a non-blocking stream, so a
+    // memset on the null stream would not be ordered against the kernels that write these targets next
+    HIPCHK(ctx, hipMemsetAsync(d.rgba32f, 0, n * 16, d.stream));
+    for (int c = 0; c < 3; c++) HIPCHK(ctx, hipMemsetAsync(d.chan[c], 0, n * 4, d.stream));
+    HIPCHK(ctx, hipMemsetAsync(d.prim_id, 0xFF, n * 4, d.stream));
+    HIPCHK(ctx, hipMemsetAsync(d.hit_t, 0, n * 4, d.stream));
     d.fb_w = w;
     d.fb_h = h;
     return RT_OK;
@@ -262,6 +263,8 @@ int upload_common(rt_ctx* ctx, const rt_sphere* spheres, uint32_t n_spheres, con
         if ((rc = upload_array(ctx, &d.spheres, ds)) != RT_OK) return rc;
         if ((rc = upload_array(ctx, &d.lights, dl)) != RT_OK) return rc;
         if ((rc = upload_array(ctx, &d.materials, dm)) != RT_OK) return rc;
+        // the copies went through the null stream and d.stream is non-blocking: make the order explicit
+        HIPCHK(ctx, hipDeviceSynchronize());
     }
     DevScene& sc = ctx->scene_counts;
     sc = DevScene{};

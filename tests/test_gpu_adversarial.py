@@ -160,3 +160,22 @@ def test_glass_with_unit_ior_and_total_internal_reflection(gpu_ctx, oracle_mod):
         g = gpu_ctx.read_rgb32f()
         assert np.array_equal(np.isnan(g), np.isnan(ext["rgb"]))
         np.testing.assert_array_equal(g[~np.isnan(g)].view(np.uint32), ext["rgb"][~np.isnan(ext["rgb"])].view(np.uint32))
+
+
+def test_target_reallocation_is_ordered_with_the_first_kernel(gpu_ctx, oracle_mod):
+    """A change of frame size reallocates and clears the targets right before the first kernel that writes them; the
+    clears must be ordered on the context's stream (a clear that lands late wipes the hit distances of a finished frame)."""
+    tris, ids = _grid(6, 6)
+    scene = _scene("realloc", tris, ids)
+    packed = oracle_mod.PackedScene(scene, use_bvh=False)
+    gpu_ctx.upload_scene(scene)
+    sizes = [(96, 64), (9, 7), (640, 360), (33, 1), (1024, 768), (128, 128)]
+    refs = {s: oracle_mod.render_frame(packed, *s, camera=scene.camera, mode=1) for s in set(sizes)}
+    for rep in range(5):
+        for w, h in sizes:
+            gpu_ctx.render(w, h, scene.camera, mode=1)
+            prim, t = gpu_ctx.read_hits()
+            ref = refs[(w, h)]
+            np.testing.assert_array_equal(prim, ref["prim"], err_msg=f"{w}x{h} rep {rep}")
+            np.testing.assert_array_equal(t.view(np.uint32), ref["t"].view(np.uint32), err_msg=f"{w}x{h} rep {rep}")
+            np.testing.assert_array_equal(gpu_ctx.read_rgba8_combined(), ref["combined"], err_msg=f"{w}x{h} rep {rep}")
