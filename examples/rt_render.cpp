@@ -34,7 +34,7 @@ static double now_ms() {
 
 static int usage(const char* argv0, int rc) {
     std::fprintf(rc ? stderr : stdout,
-                 "usage: %s [--gltf FILE.gltf|.glb] [--size WxH] [--out FILE.png|.ppm] [--spp N --bounces B] [--fly FRAMES] [--device D]\n"
+                 "usage: %s [--gltf FILE.gltf|.glb] [--size WxH] [--out FILE.png|.ppm|.exr] [--spp N --bounces B] [--fly FRAMES] [--device D]\n"
                  "  without --gltf the reference's default scene (6 spheres, 2 triangles, 1 light) is rendered;\n"
                  "  without --spp the reference path runs: progressive 128x128 tiles, three channel dispatches per tile;\n"
                  "  with --spp N the extended mode (jittered samples, shadow rays, --bounces B, default 4) runs through rt_render;\n"
@@ -168,7 +168,15 @@ int main(int argc, char** argv) {
     }
 
     const bool ppm = out.size() > 4 && out.substr(out.size() - 4) == ".ppm";
-    const bool ok = ppm ? write_ppm(out.c_str(), rgba8.data(), width, height) : write_png(out.c_str(), rgba8.data(), width, height);
+    const bool exr = out.size() > 4 && out.substr(out.size() - 4) == ".exr";
+    bool ok;
+    if (exr) { // the float image, every bit of it
+        std::vector<float> rgb((size_t)width * height * 3);
+        rc = rt_read_rgb32f(ctx, rgb.data(), rgb.size());
+        if (rc != RT_OK) return fail("rt_read_rgb32f", rc);
+        ok = write_exr(out.c_str(), rgb.data(), width, height);
+    } else
+        ok = ppm ? write_ppm(out.c_str(), rgba8.data(), width, height) : write_png(out.c_str(), rgba8.data(), width, height);
     rt_destroy(ctx);
     if (!ok) {
         std::fprintf(stderr, "cannot write %s\n", out.c_str());

@@ -219,6 +219,11 @@ int rt_host_write_png(const char* path, const uint8_t* rgba8, uint32_t width, ui
     return write_png(path, rgba8, width, height) ? RT_OK : RT_HOST_ERR_IO;
 }
 
+int rt_host_write_exr(const char* path, const float* rgb32f, uint32_t width, uint32_t height) {
+    if (!path || !rgb32f || !width || !height) return RT_ERR_BAD_ARG;
+    return write_exr(path, rgb32f, width, height) ? RT_OK : RT_HOST_ERR_IO;
+}
+
 void rt_host_progressive_timing(double out[7]) {
     for (int i = 0; i < 7; i++) out[i] = g_timing[i];
 }

@@ -144,7 +144,7 @@ def camera_move(camera, forward, right):
 
 
 HOST_SYMBOLS += ["rt_host_gltf_load", "rt_host_gltf_load_glb", "rt_host_scene_counts", "rt_host_scene_copy", "rt_host_scene_free",
-                 "rt_host_write_ppm", "rt_host_write_png", "rt_host_progressive_timing"]
+                 "rt_host_write_ppm", "rt_host_write_png", "rt_host_write_exr", "rt_host_progressive_timing"]
 GLTF_ERRORS = {-11: "IoError", -12: "GltfError", -13: "ValidationError"}
 
 
@@ -204,6 +204,17 @@ def load_glb(data, scene_index=-1):
 
 # ---- rows N3 / N4 ------------------------------------------------------------------------------------
 def write_image(path, rgba8):
+    """rgba8 (H x W x 4 uint8) to .png / .ppm, or the float image (H x W x 3 float32) to .exr."""
+    if str(path).lower().endswith(".exr"):
+        img = np.ascontiguousarray(rgba8, dtype=np.float32)
+        if img.ndim != 3 or img.shape[2] != 3:
+            raise ValueError("an .exr takes the H x W x 3 float image")
+        fn = _lib().rt_host_write_exr
+        fn.restype = C.c_int
+        rc = fn(str(path).encode(), _p(img), C.c_uint32(img.shape[1]), C.c_uint32(img.shape[0]))
+        if rc != 0:
+            raise OSError(f"cannot write {path} ({rc})")
+        return
     img = np.ascontiguousarray(rgba8, dtype=np.uint8)
     h, w = img.shape[:2]
     fn = _lib().rt_host_write_png if str(path).lower().endswith(".png") else _lib().rt_host_write_ppm

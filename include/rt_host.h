@@ -78,6 +78,8 @@ void rt_host_scene_free(rt_host_scene* s);
 /* ---- row N3: image output (the reference has none) ---- */
 int rt_host_write_ppm(const char* path, const uint8_t* rgba8, uint32_t width, uint32_t height);
 int rt_host_write_png(const char* path, const uint8_t* rgba8, uint32_t width, uint32_t height);
+/* OpenEXR (scanline, uncompressed, FLOAT R G B) of the packed float image rt_read_rgb32f returns: width*height*3 floats */
+int rt_host_write_exr(const char* path, const float* rgb32f, uint32_t width, uint32_t height);
 
 /* ---- row N4: the reference's progressive completion summary (src/compute.rs:320-363) for the last
  * rt_host_render_progressive on this thread: out[0] total ms, [1] calls, [2] tiles, [3] tiles/s,

@@ -137,6 +137,66 @@ def test_image_writers_round_trip(tmp_path):
     np.testing.assert_array_equal(rows[:, 1:].reshape(37, 53, 4), img)
 
 
+def _read_exr(raw):
+    """Minimal reader for what write_exr emits, following the OpenEXR file layout: magic, version, attributes until an
+    empty name, the line offset table, one uncompressed block per scanline with its channels stored as planes in
+    alphabetical order.  Returns (attributes, H x W x 3 float32 in R G B order)."""
+    assert raw[:4] == bytes([0x76, 0x2F, 0x31, 0x01]) and struct.unpack("<I", raw[4:8])[0] == 2
+    pos, attrs = 8, {}
+    while raw[pos] != 0:
+        end = raw.index(b"\0", pos)
+        name = raw[pos:end].decode()
+        pos = end + 1
+        end = raw.index(b"\0", pos)
+        typ = raw[pos:end].decode()
+        pos = end + 1
+        (n,) = struct.unpack("<I", raw[pos:pos + 4])
+        attrs[name] = (typ, raw[pos + 4:pos + 4 + n])
+        pos += 4 + n
+    pos += 1
+    assert attrs["compression"] == ("compression", b"\0") and attrs["lineOrder"] == ("lineOrder", b"\0")
+    x0, y0, x1, y1 = struct.unpack("<4i", attrs["dataWindow"][1])
+    assert attrs["dataWindow"][0] == "box2i" and attrs["displayWindow"] == attrs["dataWindow"] and (x0, y0) == (0, 0)
+    w, h = x1 + 1, y1 + 1
+    chl, names, q = attrs["channels"][1], [], 0
+    assert attrs["channels"][0] == "chlist"
+    while chl[q] != 0:
+        end = chl.index(b"\0", q)
+        names.append(chl[q:end].decode())
+        pixel_type, p_linear, xs, ys = struct.unpack("<iB3xii", chl[end + 1:end + 17])
+        assert (pixel_type, xs, ys) == (2, 1, 1)  # FLOAT, no subsampling
+        q = end + 17
+    assert names == sorted(names) == ["B", "G", "R"] and q == len(chl) - 1
+    offsets = struct.unpack(f"<{h}Q", raw[pos:pos + 8 * h])
+    img = np.zeros((h, w, 3), np.float32)
+    for y in range(h):
+        o = offsets[y]
+        yy, nbytes = struct.unpack("<iI", raw[o:o + 8])
+        assert yy == y and nbytes == 12 * w
+        planes = np.frombuffer(raw[o + 8:o + 8 + nbytes], "<f4").reshape(3, w)
+        img[y, :, 2], img[y, :, 1], img[y, :, 0] = planes[0], planes[1], planes[2]
+    assert offsets[-1] + 8 + 12 * w == len(raw)
+    return attrs, img
+
+
+def test_exr_writer_keeps_every_bit(tmp_path):
+    """The float image goes to OpenEXR (scanline, uncompressed, FLOAT) unchanged - NaN payloads, infinities, denormals
+    and negative zero included - so float parity diffs can be inspected outside this repository."""
+    rng = np.random.default_rng(8)
+    img = rng.standard_normal((23, 41, 3)).astype(np.float32)
+    img.view(np.uint32)[0, :6, 0] = [0x7FC00001, 0xFF800000, 0x7F800000, 0x00000001, 0x80000000, 0x7F7FFFFF]
+    host.write_image(tmp_path / "a.exr", img)
+    attrs, back = _read_exr((tmp_path / "a.exr").read_bytes())
+    np.testing.assert_array_equal(back.view(np.uint32), img.view(np.uint32))
+    assert struct.unpack("<f", attrs["pixelAspectRatio"][1])[0] == 1.0 and attrs["screenWindowCenter"][0] == "v2f"
+    host.write_image(tmp_path / "one.exr", img[:1, :1])
+    assert np.array_equal(_read_exr((tmp_path / "one.exr").read_bytes())[1].view(np.uint32), img[:1, :1].view(np.uint32))
+    with pytest.raises(ValueError):
+        host.write_image(tmp_path / "bad.exr", np.zeros((4, 4, 4), np.float32))
+    with pytest.raises(OSError):
+        host.write_image(tmp_path / "no_such_dir" / "a.exr", img)
+
+
 @pytest.mark.gpu
 def test_gltf_scene_through_the_whole_drop_in_path_on_gpu(gpu_ctx, oracle_mod, tmp_path):
     """glTF file -> GltfLoader -> BvhBuilder -> BufferManager -> ComputeRenderer::run_compute (rt_dispatch_tile per tile
@@ -209,6 +269,10 @@ def test_native_front_end_renders_the_gltf_fixture_like_the_oracle(oracle_mod, t
     img2 = np.frombuffer(raw2[len(b"P6\n160 120\n255\n"):], np.uint8).reshape(120, 160, 3)
     exp = np.clip(np.floor(np.clip(ext["rgb"], 0, 1) * 255.0 + 0.5), 0, 255).astype(np.uint8)
     np.testing.assert_array_equal(img2, exp)
+    exr = tmp_path / "ext.exr"
+    out = subprocess.run([exe, "--size", "160x120", "--spp", "4", "--bounces", "2", "--out", str(exr)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    np.testing.assert_array_equal(_read_exr(exr.read_bytes())[1].view(np.uint32), ext["rgb"].view(np.uint32))
 
 
 def test_loader_survives_mutated_files_under_asan_ubsan(tmp_path):
