@@ -1,6 +1,6 @@
 """Debug: far-origin parity (development aid)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, oracle
 from gpu_raytracer_amd import api, scenes
 scene = scenes.random_soup(900, seed=12, size=0.5, n_spheres=1, n_lights=2)

@@ -1,6 +1,6 @@
 """Quick GPU-vs-oracle parity probe (development aid; the real checks live in tests/)."""
 import sys, time, json, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import oracle
 from gpu_raytracer_amd import api, scenes

@@ -2,7 +2,7 @@
 and must be bit-identical, tile partitions must reassemble to the full frame, and small cases are compared with the CPU
 statement.  Looks for rare races in the queue machinery.  usage: soak.py <seconds>"""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, oracle
 from gpu_raytracer_amd import api, scenes
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
