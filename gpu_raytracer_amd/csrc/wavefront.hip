@@ -11,6 +11,7 @@
 // Per-path arithmetic and its order are exactly those of the CPU statement (and of the megakernels in
 // kernels.hip); queues only change WHEN a path's next step runs, so images stay bit-identical.
 #include "wavefront.h"
+#include <cstdlib>
 
 #include <algorithm>
 
@@ -656,7 +657,17 @@ int cu_count() {
 
 namespace rt {
 
-uint32_t wf_shading_blocks() { return (uint32_t)(cu_count() * 8); }
+#ifndef RT_WF_SHADE_BLOCKS_PER_CU
+#define RT_WF_SHADE_BLOCKS_PER_CU 16 /* 256-thread blocks per CU for generate / shade / finish: 4, 5, 10 measure 1-3 % slower than 8; 12…32 within 0.5 %, 16 best (-0.7 %) */
+#endif
+uint32_t wf_shading_blocks() {
+    static const int per_cu = [] {
+        const char* e = std::getenv("RT_WF_SHADE_BLOCKS_PER_CU"); // development knob
+        const int v = e ? std::atoi(e) : 0;
+        return v > 0 && v <= 64 ? v : RT_WF_SHADE_BLOCKS_PER_CU;
+    }();
+    return (uint32_t)(cu_count() * per_cu);
+}
 // Slots a queue can take up: a wave's reservations hold at least half real entries each (a request is at most half
 // the minimum window), plus one window it may leave unused at the end: <= 2 x real + waves x W, and
 // W <= max(minimum, half of what the wave can emit), so summed over the producing waves
