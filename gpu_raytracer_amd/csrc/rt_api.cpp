@@ -392,7 +392,8 @@ int run_frame(rt_ctx* ctx, DevFrame fr, bool counters, uint32_t world, uint32_t 
         if (rc != RT_OK) return rc;
         DevFrame f = fr;
         if (!single_tile) {
-            uint32_t stride = world * (uint32_t)nd, first = rank * (uint32_t)nd + (uint32_t)j;
+            // the context owns the tiles i with i % world == rank (rt_hip.h); its device j takes every nd-th of those
+            uint32_t stride = world * (uint32_t)nd, first = rank + world * (uint32_t)j;
             f.tile_first = first;
             f.tile_stride = stride;
             f.n_owned_tiles = first < total_tiles ? (total_tiles - first + stride - 1) / stride : 0;
@@ -711,6 +712,7 @@ int rt_dispatch_tile(rt_ctx* ctx, const rt_push_constants* pc) {
     d.tile_first = 0;
     d.tile_stride = 1;
     d.n_owned = ctx->frame_tiles_x * ctx->frame_tiles_y;
+    for (size_t j = 1; j < ctx->devs.size(); j++) ctx->devs[j].n_owned = 0; // whatever they own dates from an earlier rt_render
     return RT_OK;
 }
 
@@ -721,7 +723,7 @@ static int gather(rt_ctx* ctx, uint8_t* out, size_t elem, int which /*0 rgba32f,
     std::vector<uint8_t> tmp;
     for (size_t j = 0; j < ctx->devs.size(); j++) {
         DeviceState& d = ctx->devs[j];
-        if (d.fb_w != w || d.fb_h != h) continue;
+        if (d.fb_w != w || d.fb_h != h || d.n_owned == 0) continue;
         const void* src = which == 0 ? (const void*)d.rgba32f : which <= 3 ? (const void*)d.chan[which - 1] : which == 4 ? (const void*)d.prim_id : (const void*)d.hit_t;
         HIPCHK(ctx, hipSetDevice(d.device));
         bool all = d.tile_stride == 1 && d.tile_first == 0;

@@ -73,6 +73,7 @@ typedef struct rt_render_params {
     uint32_t tile_size;   /* 0 = RT_TILE_SIZE (128). Tile grid = TileHelper::calculate_tile_count    */
     uint32_t tile_rank;   /* this context renders tiles with (row-major index % tile_world) ==       */
     uint32_t tile_world;  /* tile_rank; 0/1 = all tiles. Used by one-process-per-GPU launches.       */
+                          /* A context over several devices splits those tiles among its devices.   */
     uint32_t flags;       /* RT_FLAG_*                                                               */
 } rt_render_params;
 

@@ -302,3 +302,42 @@ def test_degenerate_nodes_and_far_origins_are_safe_and_exact(gpu_ctx, oracle_mod
     ext = oracle_mod.render_extended(oracle_mod.PackedScene(scene, use_bvh=False), 64, 40, 2, 2, camera=cam)
     gpu_ctx.render(64, 40, cam, mode=2, spp=2, max_bounces=2)
     np.testing.assert_array_equal(gpu_ctx.read_rgb32f().view(np.uint32), ext["rgb"].view(np.uint32))
+
+
+def test_one_context_over_several_devices(gpu_ctx, oracle_mod):
+    """rt_create(ids, n) with n > 1: tiles interleaved over the context's devices, every device with its own stream,
+    targets and queues, the read-back gathering each device's tiles.  One GPU listed two and three times stands in for
+    several (the code path is the same): results must equal the single-device context's, which equals the oracle's."""
+    scene = scenes.random_soup(3000, seed=9, n_spheres=2, n_lights=3)
+    w, h = 400, 300  # 4 x 3 tiles with ragged right / bottom edges
+    ref = oracle_mod.render_frame(oracle_mod.PackedScene(scene, use_bvh=False), w, h, mode=1)
+    gpu_ctx.upload_scene(scene)
+    one = gpu_ctx.render(w, h, scene.camera, mode=2, spp=3, max_bounces=2, frame_seed=5, tile_size=32)
+    ext = gpu_ctx.read_rgb32f()
+    for ids in ((0, 0), (0, 0, 0)):
+        with type(gpu_ctx)(ids) as ctx:
+            got = _render_gpu(ctx, scene, w, h, mode=1)
+            _assert_bit_exact(got, ref)
+            assert got["stats"]["rays"] == w * h
+            # the tile partition of a rank on top of the in-process one
+            acc, rays = np.zeros_like(ref["rgb"]), 0
+            for rank in range(2):
+                st = ctx.render(w, h, scene.camera, mode=1, tile_rank=rank, tile_world=2)
+                part = ctx.read_rgb32f()
+                tx, ty = H.tile_count(w, h)
+                for tile in range(rank, tx * ty, 2):
+                    ox, oy = (tile % tx) * 128, (tile // tx) * 128
+                    acc[oy:oy + 128, ox:ox + 128] = part[oy:oy + 128, ox:ox + 128]
+                rays += st["rays"]
+            np.testing.assert_array_equal(acc.view(np.uint32), ref["rgb"].view(np.uint32))
+            assert rays == w * h
+            st = ctx.render(w, h, scene.camera, mode=2, spp=3, max_bounces=2, frame_seed=5, tile_size=32)
+            np.testing.assert_array_equal(ctx.read_rgb32f().view(np.uint32), ext.view(np.uint32))
+            assert (st["rays"], st["shadow_rays"]) == (one["rays"], one["shadow_rays"])
+            # a dispatch sequence on such a context is owned by its first device
+            packed = oracle_mod.PackedScene(scene, use_bvh=False)
+            tx, ty = H.tile_count(w, h)
+            for tile in range(tx * ty):
+                for ch in range(3):
+                    ctx.dispatch_tile(packed.push_constants(w, h, channel=ch, mode=1, tile_offset=((tile % tx) * 128, (tile // tx) * 128)))
+            np.testing.assert_array_equal(ctx.read_rgba8_combined(), ref["combined"])
