@@ -515,6 +515,45 @@ int run_frame(rt_ctx* ctx, DevFrame fr, bool counters, uint32_t world, uint32_t 
     return RT_OK;
 }
 
+int gather(rt_ctx* ctx, uint8_t* out, size_t elem, int which);
+
+// A dispatch sequence runs on the context's first device and starts from the textures as they are (tiles that are
+// not dispatched keep their texels, like the reference's storage textures).  After an rt_render that was split over
+// several devices those texels are spread over the devices: bring them together on the first one (a slow path through
+// host memory, taken once at the transition).
+int consolidate_on_first_device(rt_ctx* ctx, uint32_t w, uint32_t h) {
+    if (ctx->devs.size() < 2 || ctx->frame_w != w || ctx->frame_h != h) return RT_OK;
+    DeviceState& d0 = ctx->devs[0];
+    if (d0.fb_w != w || d0.fb_h != h) return RT_OK;
+    bool spread = false;
+    for (size_t j = 1; j < ctx->devs.size(); j++) spread = spread || (ctx->devs[j].n_owned > 0 && ctx->devs[j].fb_w == w && ctx->devs[j].fb_h == h);
+    if (!spread) return RT_OK;
+    for (auto& d : ctx->devs) {
+        HIPCHK(ctx, hipSetDevice(d.device));
+        HIPCHK(ctx, hipStreamSynchronize(d.stream));
+    }
+    const size_t n = (size_t)w * h;
+    std::vector<uint8_t> buf;
+    HIPCHK(ctx, hipSetDevice(d0.device));
+    for (int which = 0; which < 6; which++) {
+        const size_t elem = which == 0 ? 16 : 4;
+        void* dst = which == 0 ? (void*)d0.rgba32f : which <= 3 ? (void*)d0.chan[which - 1] : which == 4 ? (void*)d0.prim_id : (void*)d0.hit_t;
+        buf.resize(n * elem);
+        HIPCHK(ctx, hipSetDevice(d0.device));
+        HIPCHK(ctx, hipMemcpy(buf.data(), dst, n * elem, hipMemcpyDeviceToHost)); // what the first device holds outside everyone's tiles
+        int rc = gather(ctx, buf.data(), elem, which);
+        if (rc != RT_OK) return rc;
+        HIPCHK(ctx, hipSetDevice(d0.device));
+        HIPCHK(ctx, hipMemcpy(dst, buf.data(), n * elem, hipMemcpyHostToDevice));
+    }
+    HIPCHK(ctx, hipDeviceSynchronize());
+    d0.tile_first = 0;
+    d0.tile_stride = 1;
+    d0.n_owned = ctx->frame_tiles_x * ctx->frame_tiles_y;
+    for (size_t j = 1; j < ctx->devs.size(); j++) ctx->devs[j].n_owned = 0;
+    return RT_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -700,7 +739,9 @@ int rt_dispatch_tile(rt_ctx* ctx, const rt_push_constants* pc) {
     // Only texture `channel` receives texels (the other two keep theirs, as separate bind groups do);
     // the float and hit targets of the tile are refreshed as a by-product.
     DeviceState& d = ctx->devs[0];
-    int rc = run_frame(ctx, fr, false, 1, 0, true);
+    int rc = consolidate_on_first_device(ctx, w, h);
+    if (rc != RT_OK) return rc;
+    rc = run_frame(ctx, fr, false, 1, 0, true);
     if (rc != RT_OK) return rc;
     ctx->frame_w = w;
     ctx->frame_h = h;
@@ -717,7 +758,8 @@ int rt_dispatch_tile(rt_ctx* ctx, const rt_push_constants* pc) {
 }
 
 // Copy `elem` bytes per pixel of every device's owned tiles into `out` (full frame, row-major).
-static int gather(rt_ctx* ctx, uint8_t* out, size_t elem, int which /*0 rgba32f, 1..3 chan, 4 prim, 5 t*/) {
+namespace {
+int gather(rt_ctx* ctx, uint8_t* out, size_t elem, int which /*0 rgba32f, 1..3 chan, 4 prim, 5 t*/) {
     uint32_t w = ctx->frame_w, h = ctx->frame_h;
     size_t n = (size_t)w * h;
     std::vector<uint8_t> tmp;
@@ -744,6 +786,7 @@ static int gather(rt_ctx* ctx, uint8_t* out, size_t elem, int which /*0 rgba32f,
     }
     return RT_OK;
 }
+} // namespace
 
 // Whole frame on one device: run the epilogue there and bring the result back through pinned staging
 // (`which` 0: packed rgb32f, 1: combined rgba8).  Returns RT_OK, an error, or 1 when the caller must use the gather path.

@@ -341,3 +341,13 @@ def test_one_context_over_several_devices(gpu_ctx, oracle_mod):
                 for ch in range(3):
                     ctx.dispatch_tile(packed.push_constants(w, h, channel=ch, mode=1, tile_offset=((tile % tx) * 128, (tile // tx) * 128)))
             np.testing.assert_array_equal(ctx.read_rgba8_combined(), ref["combined"])
+            # tiles that a dispatch sequence leaves out keep their texels, also those another device rendered:
+            # a whole frame in mode 0 (black background), then ONE tile x channel dispatch in mode 1 (sky)
+            ref0 = oracle_mod.render_frame(packed, w, h, mode=0)
+            ctx.render(w, h, scene.camera, mode=0)
+            pc = packed.push_constants(w, h, channel=1, mode=1, tile_offset=(128, 128))
+            ctx.dispatch_tile(pc)
+            want = [ref0["red"].copy(), ref0["green"].copy(), ref0["blue"].copy()]
+            oracle_mod.dispatch(packed, pc, want[1])
+            for got_c, want_c in zip(ctx.read_rgba8_channels(), want):
+                np.testing.assert_array_equal(got_c, want_c)

@@ -2,7 +2,7 @@
 three modes, explicit tile x channel dispatches in random order (some skipped), size changes, reads in random order -
 against a CPU model of the three channel textures driven by the oracle.  Looks for ordering bugs between the
 asynchronous dispatches, target reallocation, the read-back epilogues and scene replacement.
-usage: soak_api.py <seconds>"""
+usage: soak_api.py <seconds> [devices]   devices > 1: one context over GPU 0 listed that many times (the several-device path)"""
 import os
 import sys
 import time
@@ -14,6 +14,7 @@ import oracle
 from gpu_raytracer_amd import api, scenes
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+n_dev = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(2024)
 scene_list = [scenes.default_scene(), scenes.cornell12(), scenes.random_soup(300, seed=9, size=0.5, n_spheres=2, n_lights=2), scenes.empty_scene()]
 packs = [oracle.PackedScene(s, use_bvh=False) for s in scene_list]  # brute force: ties resolve to the lowest index
@@ -30,7 +31,7 @@ def eq(a, b, label=""):
     return same
 
 
-with api.Context() as ctx:
+with api.Context((0,) * n_dev) as ctx:
     si = 0
     ctx.upload_scene(scene_list[si])
     size, model = None, None  # model: [red, green, blue] H x W x 4 uint8, or None when unknown (after an extended render)
