@@ -1,16 +1,17 @@
 """Soak test (development aid): many renders with random shapes / sample counts / partitions; every render is repeated
 and must be bit-identical, tile partitions must reassemble to the full frame, and small cases are compared with the CPU
-statement.  Looks for rare races in the queue machinery.  usage: soak.py <seconds>"""
+statement.  Looks for rare races in the queue machinery.  usage: soak.py <seconds> [devices]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, oracle
 from gpu_raytracer_amd import api, scenes
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+n_dev = int(sys.argv[2]) if len(sys.argv) > 2 else 1  # > 1: one context over GPU 0 listed that many times
 rng = np.random.default_rng(12345)
 scene_list = [scenes.sponza_like(), scenes.random_soup(5000, seed=4, size=0.3, n_spheres=2, n_lights=5), scenes.cornell12(), scenes.default_scene()]
 t_end = time.time() + budget
 it = bad = 0
-with api.Context() as ctx:
+with api.Context((0,) * n_dev) as ctx:
     while time.time() < t_end:
         sc = scene_list[rng.integers(len(scene_list))]
         ctx.upload_scene(sc)
