@@ -351,3 +351,27 @@ def test_one_context_over_several_devices(gpu_ctx, oracle_mod):
             oracle_mod.dispatch(packed, pc, want[1])
             for got_c, want_c in zip(ctx.read_rgba8_channels(), want):
                 np.testing.assert_array_equal(got_c, want_c)
+
+
+def test_packed_upload_with_triangles_spread_over_three_buffers(gpu_ctx, oracle_mod):
+    """rt_upload_scene_packed takes the reference's three triangle buffers (src/buffers.rs:243-330): triangle i lives in
+    buffer i / triangles_per_buffer.  A small triangles_per_buffer spreads a soup over all three, with a ragged last
+    buffer and an empty one; the result must equal the unpacked upload's and the oracle's."""
+    scene = scenes.random_soup(2500, seed=21, size=0.4, n_spheres=1, n_lights=2)
+    w, h = 200, 150
+    gpu_ctx.upload_scene(scene)
+    gpu_ctx.render(w, h, scene.camera, mode=1)
+    want_prim, want_t = gpu_ctx.read_hits()
+    want_rgb = gpu_ctx.read_rgb32f()
+    for tpb in (1000, 1250, 2500, 4000):  # 3 ragged buffers / 2 full + 1 empty / 1 full + 2 empty / 1 partly filled
+        packed = oracle_mod.PackedScene(scene, use_bvh=False, triangles_per_buffer=tpb)
+        ref = oracle_mod.render_frame(packed, w, h, mode=1)
+        with type(gpu_ctx)() as ctx:
+            ctx.upload_scene_packed(packed.metadata, packed.offsets, packed.tri_bufs, packed.triangles_per_buffer, scene.materials)
+            ctx.render(w, h, scene.camera, mode=1)
+            prim, t = ctx.read_hits()
+            np.testing.assert_array_equal(prim, want_prim, err_msg=f"tpb {tpb}")
+            np.testing.assert_array_equal(t.view(np.uint32), want_t.view(np.uint32))
+            np.testing.assert_array_equal(ctx.read_rgb32f().view(np.uint32), want_rgb.view(np.uint32))
+            np.testing.assert_array_equal(prim, ref["prim"])
+            np.testing.assert_array_equal(ctx.read_rgba8_combined(), ref["combined"])
