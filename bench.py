@@ -5,19 +5,26 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one frame of synthetic input: the sponza-like scene
-(262,144 triangles, seed 0x53504F4E) at 1920x1080 (BASELINE.json's headline workload), scene already
-resident in HBM.  With N ranks the frame's 128x128 tiles are interleaved over the ranks (tile i ->
-rank i mod N, scene replicated, no data-path collective); torch.distributed is used only for the
-barrier and the max-over-ranks of the timed region.  Rank 0 prints ONE JSON line.
+A "step" is one pass of the hot path over one frame of synthetic input: the sponza-like scene (262,144 triangles,
+seed 0x53504F4E) at 1920x1080, 64 spp (BASELINE.json's headline workload), scene already resident in HBM.  With N
+ranks the frame's 32x32 tiles are interleaved over the ranks (tile i -> rank i mod N, scene replicated, no data-path
+collective); torch.distributed carries only the barrier and the max / sum of a few scalars.  After the timed region
+every rank copies its tiles into one shared host framebuffer and rank 0 prints the CRC of the assembled float image:
+it is the same number for every N (a pixel does not depend on the partition).  Rank 0 prints ONE JSON line.
+
+`value` follows the written metric: a ray is one traced segment, primary (camera) or
+continuation.  The extended mode also traces shadow segments toward every light with a non-zero contribution; they
+are real any-hit BVH walks and are reported beside it (`all_segments_mrays_per_s`), not inside it.
 
 There is no CPU fallback: without librt_hip.so or a HIP device this script fails.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
 import time
+import zlib
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -27,7 +34,16 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 S_OUT_BYTES = 16 + 12 + 8  # per pixel: RGBA32F + three unorm8 texels + (prim id, t) hit record
-S_STATE_BYTES = 2 * 76  # per segment through the wavefront queues: one WavefrontRay-sized record written and read
+
+# Path-state bytes the queue pipeline moves per segment KIND (gpu_raytracer_amd/csrc/wavefront.hip; 16-byte records):
+#   extension segment (camera or continuation): written by generate/finish: ray_o, ray_d, thr, rad (64) + queue id (4);
+#     read by the closest-hit walk: id (4) + ray_o, ray_d (32), writes the hit record (16); the shade stage reads
+#     id + hit (20) and writes vtx_p, vtx_n (32); the finish stage reads id + vtx_p, vtx_n, thr, rad, ray_d (84)
+#   shadow segment: queue entry written and read (8) + vtx_p, vtx_n read (32) + one visibility bit (atomicOr, 4)
+#   path: the sample's radiance written once and read once by the resolve (32) + pxy (4)
+S_STATE_EXTENSION = 64 + 4 + 4 + 32 + 16 + 20 + 32 + 84
+S_STATE_SHADOW = 8 + 32 + 4
+S_STATE_PATH = 32 + 4
 
 
 def parse_args():
@@ -47,7 +63,8 @@ def parse_args():
     ap.add_argument("--cpu-sample", default=None, help="resolution of the bounded CPU-baseline sample (default 960x540 "
                     "for the reference mode, 160x90 at <= 4 spp for the extended mode)")
     ap.add_argument("--selftest-cpu", action="store_true",
-                    help="exercise only the multi-process glue (tile partition, barrier, max-reduce) on CPU/gloo; renders nothing")
+                    help="exercise only the multi-process glue (tile partition, barrier, max-reduce, frame assembly + CRC) on "
+                         "CPU/gloo with a synthetic frame; renders nothing")
     return ap.parse_args()
 
 
@@ -72,22 +89,21 @@ def owned_tiles(width, height, tile, rank, world):
     return list(range(rank, tx * ty, world)), tx, ty
 
 
-def max_over_ranks(dist, value, device):
+def _reduce(dist, value, device, op):
     if dist is None:
         return value
     import torch
     t = torch.tensor([value], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(t, op=getattr(dist.ReduceOp, op))
     return float(t.item())
+
+
+def max_over_ranks(dist, value, device):
+    return _reduce(dist, value, device, "MAX")
 
 
 def sum_over_ranks(dist, value, device):
-    if dist is None:
-        return value
-    import torch
-    t = torch.tensor([value], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return float(t.item())
+    return _reduce(dist, value, device, "SUM")
 
 
 def barrier_sync(dist, torch_cuda):
@@ -95,6 +111,44 @@ def barrier_sync(dist, torch_cuda):
         dist.barrier()
     if torch_cuda is not None:
         torch_cuda.synchronize()
+
+
+def assemble_frame(dist, rank, world, local_frame, width, height, tile):
+    """SURVEY §8e "gather": every rank copies its disjoint tiles (D2H already done: local_frame is this rank's read-back,
+    zero outside its tiles) into ONE host framebuffer shared by the ranks of the node (a /dev/shm mapping named after
+    the rendezvous port); rank 0 returns (crc32 of the float image, the image), the others (None, None).  No collective
+    moves pixels."""
+    frame_bytes = height * width * 3 * 4
+    if dist is None:
+        img = np.ascontiguousarray(local_frame, dtype=np.float32)
+        return zlib.crc32(img.tobytes()) & 0xFFFFFFFF, img
+    path = f"/dev/shm/rt_bench_fb_{os.environ.get('MASTER_PORT', '0')}_{os.getuid()}"
+    if rank == 0:
+        with open(path, "wb") as f:
+            f.truncate(frame_bytes)
+    dist.barrier()
+    fb = np.memmap(path, dtype=np.float32, mode="r+", shape=(height, width, 3))
+    tiles, tx, _ = owned_tiles(width, height, tile, rank, world)
+    for t in tiles:
+        ox, oy = (t % tx) * tile, (t // tx) * tile
+        fb[oy:oy + tile, ox:ox + tile] = local_frame[oy:oy + tile, ox:ox + tile]
+    fb.flush()
+    dist.barrier()
+    out = (None, None)
+    if rank == 0:
+        img = np.array(fb)
+        out = (zlib.crc32(img.tobytes()) & 0xFFFFFFFF, img)
+    del fb
+    dist.barrier()
+    if rank == 0:
+        os.unlink(path)
+    return out
+
+
+def synthetic_frame(width, height):
+    """A frame that is a pure function of the pixel coordinates (the --selftest-cpu stand-in for a rendered one)."""
+    y, x = np.mgrid[0:height, 0:width].astype(np.float32)
+    return np.stack([x * 0.25 + y, x - y * 0.5, (x * 7.0 + y * 13.0) % 31.0], axis=-1).astype(np.float32)
 
 
 def available_cpus():
@@ -115,46 +169,44 @@ def cpu_baseline(scene, camera, sample, mode_name, spp, bounces):
     """The oracle timed on this host's cores on a BOUNDED sample of the same workload.
     reference mode: the CPU restatement of the reference kernel walking the reference-format BVH (chunked
     mesh-order leaves, no t-culling: what the reference's kernel executes per ray).
-    extended mode: the CPU statement of the extended mode (same reference-format BVH traversal per segment)."""
+    extended mode: the CPU statement of the extended mode (same reference-format BVH traversal per segment).
+    `value` counts camera + continuation segments, like the headline value."""
     import oracle
     w, h = (int(v) for v in sample.split("x"))
     cores = available_cpus()
     packed = oracle.PackedScene(scene)
-    t0 = time.perf_counter()
-    if mode_name == "extended":
-        sspp = min(spp, 4)
-        r = oracle.render_extended(packed, w, h, sspp, bounces, camera=camera, threads=cores)
-        rays = sum(r["segments"][k] for k in ("camera", "continuation", "shadow"))
-        what = f"{sspp} spp {bounces} bounces extended mode"
-    else:
-        # 32x32 work items so every thread stays busy; the image does not depend on the tile size
-        r = oracle.render_frame(packed, w, h, camera=camera, mode=1, threads=cores, want_rgba8=False, tile_size=32)
-        rays = r["counters"]["rays"]
-        what = "1 spp primary rays"
-    dt = time.perf_counter() - t0
-    out = {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+
+    def run(p, ww, hh):
+        t0 = time.perf_counter()
+        if mode_name == "extended":
+            r = oracle.render_extended(p, ww, hh, min(spp, 4), bounces, camera=camera, threads=cores)
+            seg = r["segments"]
+            metric, allseg = seg["camera"] + seg["continuation"], seg["camera"] + seg["continuation"] + seg["shadow"]
+        else:
+            # 32x32 work items so every thread stays busy; the image does not depend on the tile size
+            r = oracle.render_frame(p, ww, hh, camera=camera, mode=1, threads=cores, want_rgba8=False, tile_size=32)
+            metric = allseg = r["counters"]["rays"]
+        return r, metric, allseg, time.perf_counter() - t0
+
+    r, metric, allseg, dt = run(packed, w, h)
+    what = f"{min(spp, 4)} spp {bounces} bounces extended mode" if mode_name == "extended" else "1 spp primary rays"
+    out = {"value": metric / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+           "all_segments_mrays_per_s": allseg / dt / 1e6,
            "sample": f"{scene.name} {w}x{h} {what}, same camera, reference-format BVH ({len(packed.nodes)} nodes, no t-culling), "
-                     f"{rays} segments in {dt:.2f} s",
+                     f"{metric} camera+continuation of {allseg} segments in {dt:.2f} s",
            "nodes_per_ray": r["counters"]["node_visits"] / max(r["counters"]["rays"], 1),
            "tris_per_ray": r["counters"]["tri_tests"] / max(r["counters"]["rays"], 1)}
     # second flavour (SURVEY 8d ii): what the same cores do with a decent traversal - one triangle per leaf, children
     # slab-tested against the closest hit, near child first, any-hit shadow segments.  Not the reference's algorithm
     # (tests/test_oracle_extended.py shows it renders the same frames); a larger sample because it is ~100x faster.
     try:
-        fw, fh = w * 4, h * 4
         fast = oracle.PackedScene(scene, bvh=oracle.build_bvh(scene.triangles, scene.vertices, per_triangle=True))
         oracle.set_fast_traversal(True)
-        t0 = time.perf_counter()
-        if mode_name == "extended":
-            r2 = oracle.render_extended(fast, fw, fh, sspp, bounces, camera=camera, threads=cores)
-            rays2 = sum(r2["segments"][k] for k in ("camera", "continuation", "shadow"))
-        else:
-            r2 = oracle.render_frame(fast, fw, fh, camera=camera, mode=1, threads=cores, want_rgba8=False, tile_size=32)
-            rays2 = r2["counters"]["rays"]
-        dt2 = time.perf_counter() - t0
-        out["culled_traversal"] = {"value": rays2 / dt2 / 1e6, "unit": "Mrays/s", "cores": cores,
-                                   "sample": f"{fw}x{fh}, {len(fast.nodes)}-node one-triangle-per-leaf BVH, ordered + distance-culled traversal, "
-                                             f"{rays2} segments in {dt2:.2f} s",
+        r2, metric2, allseg2, dt2 = run(fast, w * 4, h * 4)
+        out["culled_traversal"] = {"value": metric2 / dt2 / 1e6, "unit": "Mrays/s", "cores": cores,
+                                   "all_segments_mrays_per_s": allseg2 / dt2 / 1e6,
+                                   "sample": f"{w * 4}x{h * 4}, {len(fast.nodes)}-node one-triangle-per-leaf BVH, ordered + distance-culled "
+                                             f"traversal, {metric2} camera+continuation of {allseg2} segments in {dt2:.2f} s",
                                    "nodes_per_ray": r2["counters"]["node_visits"] / max(r2["counters"]["rays"], 1),
                                    "tris_per_ray": r2["counters"]["tri_tests"] / max(r2["counters"]["rays"], 1)}
     finally:
@@ -162,15 +214,29 @@ def cpu_baseline(scene, camera, sample, mode_name, spp, bounces):
     return out
 
 
-def load_traffic(workload):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/traffic.json), or None."""
+def kernel_source_sha16():
+    """Identity of the device code a committed counter profile belongs to: sha256 over the sources librt_hip.so is built from."""
+    csrc = os.path.join(ROOT, "gpu_raytracer_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(csrc)):
+        p = os.path.join(csrc, name)
+        if os.path.isfile(p) and name.endswith((".hip", ".h", ".cpp")):
+            h.update(name.encode())
+            h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_profile(workload):
+    """The committed rocprofv3 --pmc summary for this workload (profiles/traffic.json, written by scripts/summarize_profile.py)
+    if it was taken from THIS build of the kernels, else None."""
     p = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(p):
-        try:
-            return json.load(open(p)).get(workload)
-        except Exception:
-            return None
-    return None
+    try:
+        e = json.load(open(p)).get(workload)
+    except Exception:
+        return None
+    if not isinstance(e, dict) or e.get("source_sha16") != kernel_source_sha16():
+        return None
+    return e
 
 
 def main():
@@ -192,9 +258,17 @@ def main():
         barrier_sync(dist, None)
         dt = max_over_ranks(dist, time.perf_counter() - t0, "cpu")
         total = sum_over_ranks(dist, float(len(tiles)), "cpu")
+        # frame assembly on CPU buffers: this rank "rendered" the synthetic frame on its own tiles only
+        full = synthetic_frame(args.width, args.height)
+        mine = np.zeros_like(full)
+        for t in tiles:
+            ox, oy = (t % tx) * tile, (t // tx) * tile
+            mine[oy:oy + tile, ox:ox + tile] = full[oy:oy + tile, ox:ox + tile]
+        crc, img = assemble_frame(dist, rank, n_gpus, mine, args.width, args.height, tile)
         if rank == 0:
             print(json.dumps({"selftest": True, "n_ranks": n_gpus, "tiles_total": int(total), "tiles_expected": tx * ty,
-                              "max_dt": dt}))
+                              "max_dt": dt, "frame_crc": crc, "frame_crc_expected": zlib.crc32(full.tobytes()) & 0xFFFFFFFF,
+                              "frame_equal": bool(np.array_equal(img, full))}))
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -204,7 +278,7 @@ def main():
         raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
     local_rank = int(os.environ.get("RT_BENCH_DEVICE", local_rank))
     torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank) if dist is None or dist.get_backend() != "gloo" else "cpu"
 
     from gpu_raytracer_amd import api, scenes
     scene = scenes.SCENES[args.scene]()
@@ -227,34 +301,82 @@ def main():
         step()
     barrier_sync(dist, torch.cuda)
     t0 = time.perf_counter()
-    kernel_ms, rays = [], 0
+    kernel_ms, seg = [], np.zeros(3)
     for _ in range(args.steps):
         st = step()
         kernel_ms.append(st["kernel_ms"])
-        rays += st["rays"]
+        seg += (st["primary_rays"], st["continuation_rays"], st["shadow_rays"])
     barrier_sync(dist, torch.cuda)
     dt = max_over_ranks(dist, time.perf_counter() - t0, dev)
-    total_rays = sum_over_ranks(dist, float(rays), dev)
+    total_seg = [sum_over_ranks(dist, float(v), dev) for v in seg]  # camera, continuation, shadow over all ranks and steps
+    metric_rays, all_rays = total_seg[0] + total_seg[1], sum(total_seg)
 
-    # algorithmic bytes of one launch on this rank: exact node / triangle fetch counts from the counting variant
+    # SURVEY §8e gather, outside the timed region: D2H of this rank's tiles, then one shared host framebuffer
+    barrier_sync(dist, torch.cuda)
+    g0 = time.perf_counter()
+    crc, _img = assemble_frame(dist, rank, n_gpus, ctx.read_rgb32f(), args.width, args.height, tile)
+    gather_ms = max_over_ranks(dist, (time.perf_counter() - g0) * 1e3, dev)
+
+    # exact node / triangle fetch counts and wave-level step statistics from the counting variant of the same kernels
     stc = step(counters=True)
-    alg_bytes = stc["node_visits"] * stc["node_bytes"] + stc["tri_tests"] * stc["tri_bytes"] + stc["pixels"] * S_OUT_BYTES
-    if mode_name == "extended" and args.kernel == "wavefront":
-        alg_bytes += stc["rays"] * S_STATE_BYTES
+    diag = list(ctx.debug_counters().values())
     avg_kernel_ms = float(np.mean(kernel_ms))
-    achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
+    ext_segments = stc["primary_rays"] + stc["continuation_rays"]
+    wavefront = mode_name == "extended" and args.kernel == "wavefront"
+    fetch_bytes = stc["node_visits"] * stc["node_bytes"] + stc["tri_tests"] * stc["tri_bytes"]
+    state_bytes = (ext_segments * S_STATE_EXTENSION + stc["shadow_rays"] * S_STATE_SHADOW + stc["primary_rays"] * S_STATE_PATH) if wavefront else 0
+    # SURVEY §8d's algorithmic bytes: every record fetch + the path state + the pixels.  The scene (23 MB) is cache
+    # resident, so most of this never reaches HBM: it is reported as a rate, not as a fraction of the HBM peak.
+    alg_bytes = fetch_bytes + state_bytes + stc["pixels"] * S_OUT_BYTES
+    # bytes that have to cross the HBM interface whatever the caches do: the path state, the pixels, the scene once
+    compulsory_bytes = state_bytes + stc["pixels"] * S_OUT_BYTES + stc["scene_bytes"]
 
-    # PMC HBM bytes per launch were measured for the whole frame on one GPU (profiles/traffic.json); rank 0's share of a
-    # partitioned frame is scaled by its share of the segments
-    traffic = load_traffic(f"{scene.name}_{args.width}x{args.height}_{mode_name}")
-    if traffic is not None and n_gpus > 1 and total_rays > 0:
-        traffic = traffic * stc["rays"] / (total_rays / args.steps)
+    workload_key = f"{scene.name}_{args.width}x{args.height}_{mode_name}"
+    prof = load_profile(workload_key) if (args.spp, args.bounces) == (64, 4) or mode_name != "extended" else None
+    traffic = prof["traffic"] if prof else None
+    if traffic is not None and n_gpus > 1 and all_rays > 0:  # measured for the whole frame on one GPU: rank 0's share by segments
+        traffic = traffic * stc["rays"] / (all_rays / args.steps)
     if rank == 0:
         workload = f"{scene.name} {scene.n_triangles} tris {args.width}x{args.height} {spp} spp " + \
                    (f"{bounces} bounces (extended mode)" if mode_name == "extended" else
                     "primary rays, reference semantics (mode 1: one pixel-centre ray per pixel; the reference has no spp/bounces)")
+        achieved_bytes, achieved_src = (traffic, f"rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/traffic.json@{prof['source_sha16']}") if traffic is not None else \
+            (compulsory_bytes, "no counter profile for this build of the kernels: path-state + pixel + scene bytes that must cross HBM (lower bound)")
+        achieved = achieved_bytes / (avg_kernel_ms * 1e-3) / 1e9
+        roofline = {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "achieved_source": achieved_src,
+            "traffic": traffic, "traffic_source": f"profiles/traffic.json@{prof['source_sha16']} ({prof.get('profile', '')})" if prof else None,
+            "hbm_counter_frac": (traffic / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic is not None else None,
+            "kernel": "k_render_reference" if mode_name == "reference" else
+                      "wavefront pipeline, all stage kernels of one frame (k_wf_trace<shadow> + k_wf_trace<closest> + k_wf_shade + k_wf_finish + k_wf_generate + k_wf_resolve)",
+            "kernel_avg_ms": avg_kernel_ms,
+            "compulsory_hbm_bytes_per_launch": compulsory_bytes,
+            "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_GBps": alg_bytes / (avg_kernel_ms * 1e-3) / 1e9,
+            "state_bytes_per_segment": {"extension": S_STATE_EXTENSION, "shadow": S_STATE_SHADOW, "path": S_STATE_PATH} if wavefront else None,
+            "nodes_per_ray": stc["node_visits"] / max(stc["rays"], 1), "tris_per_ray": stc["tri_tests"] / max(stc["rays"], 1),
+            "practical_bound": "VALU issue of the two traversal kernels (branchy scalar f32, no MFMA): the scene is cache resident, HBM "
+                               "carries path state only; see `issue`",
+            "note": "launch = one frame on rank 0 (all stage kernels, HIP events on the launch stream).  achieved/frac: HBM-side bytes "
+                    "from the committed PMC passes of this very build (FETCH_SIZE is uncalibrated for 16-byte gathers, "
+                    "MI355X_MICROARCH.md).  algorithmic_*: SURVEY 8d's per-segment figure (node fetches x 48 B + triangle fetches x "
+                    "48 B + per-kind path state + pixels x 36 B); ~90 % of it is served by L1/L2, so it is a rate, not an HBM fraction",
+        }
+        if wavefront and diag[3] > 0:
+            roofline["issue"] = {
+                "node_step_lane_utilisation": stc["node_visits"] / (diag[3] * 64.0),
+                "triangle_step_lane_utilisation": diag[5] / max(diag[4] * 64.0, 1.0),
+                "triangle_trips_per_step": diag[6] / max(diag[4], 1),
+                "segments_per_refill_per_wave": stc["rays"] / max(diag[7], 1),
+                "stack_high_water": diag[0],
+                "valu_busy_from_profile": prof.get("valu_busy") if prof else None,
+                "source": "RT_FLAG_COUNTERS variant of the same kernels (this run); valu_busy = 4 x SQ_ACTIVE_INST_VALU / (kernel time x "
+                          "2.4 GHz x 1024 SIMDs) from the committed SQ pass",
+            }
+        if prof and prof.get("dominant_kernel"):
+            roofline["dominant_kernel"] = prof["dominant_kernel"]
         out = {
-            "metric": "Mrays/s", "value": total_rays / dt / 1e6, "unit": "Mrays/s",
+            "metric": "Mrays/s", "value": metric_rays / dt / 1e6, "unit": "Mrays/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -263,19 +385,14 @@ def main():
                        "implementation": args.kernel if mode_name == "extended" else "k_render_reference",
                        "partition": f"tiles {tile}x{tile} interleaved over {n_gpus} rank(s), scene replicated, no collective",
                        "bounces": bounces if mode_name == "extended" else 0,
-                       "rays_per_step": total_rays / args.steps,
-                       "mrays_per_s_camera_and_continuation_only": total_rays / dt / 1e6 * (stc["primary_rays"] + stc["continuation_rays"]) / max(stc["rays"], 1),
-                       "segments_rank0": {"camera": stc["primary_rays"], "continuation": stc["continuation_rays"], "shadow": stc["shadow_rays"]},
-                       "kernel_mrays_per_s_rank0": stc["rays"] / avg_kernel_ms / 1e3},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_render_reference" if mode_name == "reference" else
-                                   "wavefront pipeline (k_wf_trace<shadow> + k_wf_trace<closest> + k_wf_shade + k_wf_finish + k_wf_generate)",
-                         "kernel_avg_ms": avg_kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                         "nodes_per_ray": stc["node_visits"] / max(stc["rays"], 1), "tris_per_ray": stc["tri_tests"] / max(stc["rays"], 1),
-                         "note": "algorithmic bytes = node fetches x 48 B + triangle fetches x 48 B + pixels x 36 B + (wavefront) segments x 152 B of "
-                                 "queue state (rank 0's share); kernel_avg_ms is the HIP-event time of all stage kernels of one frame; "
-                                 "the 23 MB scene is cache resident, so this exceeds what HBM itself moves (see traffic)"},
+                       "ray_definition": "value counts camera + continuation segments (BASELINE.md 3); shadow segments are traced too and reported in all_segments_mrays_per_s",
+                       "all_segments_mrays_per_s": all_rays / dt / 1e6,
+                       "paths_per_s": total_seg[0] / dt,
+                       "segments_per_step": {"camera": total_seg[0] / args.steps, "continuation": total_seg[1] / args.steps, "shadow": total_seg[2] / args.steps},
+                       "kernel_mrays_per_s_rank0": ext_segments / avg_kernel_ms / 1e3,
+                       "frame_crc": crc, "gather_ms": gather_ms,
+                       "megakernel_fallback": bool(stc.get("flags", 0) & 1)},
+            "roofline": roofline,
         }
         if n_gpus == 1 and not args.no_cpu_baseline:
             sample = args.cpu_sample or ("160x90" if mode_name == "extended" else "960x540")

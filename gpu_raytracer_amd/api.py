@@ -25,7 +25,7 @@ EXTENDED_AVAILABLE = True
 
 # every symbol include/rt_hip.h declares
 ABI_SYMBOLS = [
-    "rt_create", "rt_upload_scene", "rt_upload_scene_packed", "rt_render", "rt_dispatch_tile",
+    "rt_create", "rt_upload_scene", "rt_upload_scene_packed", "rt_upload_textures", "rt_render", "rt_dispatch_tile",
     "rt_read_rgb32f", "rt_read_rgba8_channels", "rt_read_rgba8_combined", "rt_read_hits",
     "rt_get_stats", "rt_last_error", "rt_destroy", "rt_version",
 ]
@@ -119,6 +119,12 @@ class Context:
         self._check(self.lib.rt_upload_scene_packed(
             self._h, _p(md), C.c_size_t(md.size), _p(off), ptrs, counts, C.c_uint32(triangles_per_buffer),
             _p(ma), C.c_uint32(len(ma))))
+
+    def upload_textures(self, textures, texture_data):
+        """Bindings 6-7 (TextureInfo[] + texture bytes): validated and recorded, never sampled (as in the reference)."""
+        ti = np.ascontiguousarray(textures, dtype=T.TEXTURE_INFO)
+        td = np.ascontiguousarray(texture_data, dtype=np.uint8)
+        self._check(self.lib.rt_upload_textures(self._h, _p(ti), C.c_uint32(len(ti)), _p(td), C.c_size_t(td.size)))
 
     # -- rendering -------------------------------------------------------------------
     def render(self, width, height, camera, mode=MODE_LEGACY, spp=1, max_bounces=4, frame_seed=0, tile_size=0,

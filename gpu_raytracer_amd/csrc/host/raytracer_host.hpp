@@ -208,6 +208,44 @@ inline Aabb bounding_box(const Triangle& t, const Vertex* vertices) { // :671-68
 }
 } // namespace triangle
 
+// branchless_float_if! / branchless_u32_if! (shared/src/lib.rs:1293-1326).  The shader never uses them; they are part of
+// the `shared` crate's surface and its unit tests pin their NaN behaviour.  f32::min returns the non-NaN operand = fminf.
+namespace branchless {
+inline float float_if_nonnan(bool condition, float if_true, float if_false) { // the `@nonnan` arm, :1314-1316
+    return (float)(uint32_t)condition * if_true + (float)(((uint32_t)condition) ^ 1u) * if_false;
+}
+struct FloatIf {
+    float value;
+    bool valid;
+};
+inline FloatIf float_if(bool condition, float if_true, float if_false) { // :1295-1313 with max_val = f32::MAX, max_minus_one = f32::MAX - 1.0, lt
+    const float max_val = 3.402823466e+38f, max_minus_one = max_val - 1.0f;
+    const float actual_if_true = std::fmin(if_true, max_val); // a NaN operand becomes max_val
+    const float actual_if_false = std::fmin(if_false, max_val);
+    const float true_contrib = float_if_nonnan(actual_if_true < max_minus_one, actual_if_true, actual_if_false);
+    const float false_contrib = float_if_nonnan(actual_if_false < max_minus_one, actual_if_false, actual_if_true);
+    const float res = float_if_nonnan(condition, true_contrib, false_contrib);
+    return FloatIf{res, res < max_minus_one};
+}
+inline uint32_t u32_if(bool condition, uint32_t if_true, uint32_t if_false) { // :1319-1326
+    return if_true ^ ((if_true ^ if_false) & ((0u + (1u * (uint32_t)condition)) - 1u));
+}
+} // namespace branchless
+
+// BvhTriangle (src/bvh.rs:16-38): the builder's per-triangle wrapper; centroid in the reference's operation order
+struct BvhTriangle {
+    Triangle triangle;
+    size_t node_index;
+};
+namespace bvh_triangle {
+inline BvhTriangle new_(const Triangle& t, size_t node_index) { return BvhTriangle{t, node_index}; } // :22-24
+inline void centroid(const BvhTriangle& b, const Vertex* vertices, float out[3]) {                    // :27-37
+    const float *v0 = vertices[b.triangle.v0_index].position, *v1 = vertices[b.triangle.v1_index].position, *v2 = vertices[b.triangle.v2_index].position;
+    for (int i = 0; i < 3; i++) out[i] = (v0[i] + v1[i] + v2[i]) / 3.0f;
+}
+inline Aabb aabb(const BvhTriangle& b, const Vertex* vertices) { return triangle::bounding_box(b.triangle, vertices); } // BvhTriangleWithVertices::aabb, :47-55
+} // namespace bvh_triangle
+
 struct TriangleLegacy { // :133-140
     float v0[3];
     uint32_t material_id;

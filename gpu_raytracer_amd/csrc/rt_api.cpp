@@ -64,6 +64,9 @@ struct rt_ctx {
     uint32_t frame_w = 0, frame_h = 0, frame_tile = RT_TILE_SIZE, frame_tiles_x = 0, frame_tiles_y = 0;
     bool frame_valid = false;
     unsigned long long diag[8] = {0}; // diagnostics of the counting kernel variant (rt_debug_counters)
+    int fail_upload_at = -1;          // test hook: the next scene upload fails before its k-th device array (rt_debug_fail_upload)
+    uint32_t n_textures = 0;          // bindings 6-7 as last handed over (rt_upload_textures); never sampled, like the reference
+    uint64_t texture_bytes = 0;
 
     int fail(int code, const char* fmt, ...) {
         char buf[512];
@@ -254,18 +257,39 @@ int upload_common(rt_ctx* ctx, const rt_sphere* spheres, uint32_t n_spheres, con
         dm[i]._pad[0] = dm[i]._pad[1] = 0.0f;
     }
 
-    for (auto& d : ctx->devs) {
-        free_scene(d);
+    // From here on the old scene is gone: the context counts as "nothing uploaded" until EVERY device holds the whole new
+    // scene, so a failure half way (out of memory on the triangles, or on the second device) leaves no stale counts
+    // pointing at freed or partly filled arrays - the next rt_render answers RT_ERR_NOT_UPLOADED.
+    ctx->uploaded = false;
+    ctx->frame_valid = false;
+    ctx->scene_counts = DevScene{};
+    for (auto& d : ctx->devs) free_scene(d);
+    auto upload_all = [&](DeviceState& d) -> int {
         HIPCHK(ctx, hipSetDevice(d.device));
         int rc;
+        int k = 0;
+        auto hook = [&]() { return ctx->fail_upload_at >= 0 && ctx->fail_upload_at == k++; }; // test hook (rt_debug_fail_upload)
+        if (hook()) return ctx->fail(RT_ERR_OOM, "rt_upload: allocation failure injected by rt_debug_fail_upload");
         if ((rc = upload_array(ctx, &d.nodes, bvh.nodes)) != RT_OK) return rc;
+        if (hook()) return ctx->fail(RT_ERR_OOM, "rt_upload: allocation failure injected by rt_debug_fail_upload");
         if ((rc = upload_array(ctx, &d.tris, bvh.tris)) != RT_OK) return rc;
+        if (hook()) return ctx->fail(RT_ERR_OOM, "rt_upload: allocation failure injected by rt_debug_fail_upload");
         if ((rc = upload_array(ctx, &d.spheres, ds)) != RT_OK) return rc;
         if ((rc = upload_array(ctx, &d.lights, dl)) != RT_OK) return rc;
         if ((rc = upload_array(ctx, &d.materials, dm)) != RT_OK) return rc;
         // the copies went through the null stream and d.stream is non-blocking: make the order explicit
         HIPCHK(ctx, hipDeviceSynchronize());
+        return RT_OK;
+    };
+    for (auto& d : ctx->devs) {
+        const int rc = upload_all(d);
+        if (rc != RT_OK) {
+            ctx->fail_upload_at = -1;
+            for (auto& e : ctx->devs) free_scene(e);
+            return rc;
+        }
     }
+    ctx->fail_upload_at = -1;
     DevScene& sc = ctx->scene_counts;
     sc = DevScene{};
     sc.n_nodes = (uint32_t)bvh.nodes.size();
@@ -283,6 +307,8 @@ int upload_common(rt_ctx* ctx, const rt_sphere* spheres, uint32_t n_spheres, con
     ctx->stats.bvh_nodes = sc.n_nodes;
     ctx->stats.bvh_depth = bvh.depth;
     ctx->stats.n_devices = (uint32_t)ctx->devs.size();
+    ctx->stats.n_textures = ctx->n_textures;
+    ctx->stats.texture_bytes = ctx->texture_bytes;
     ctx->uploaded = true;
     ctx->frame_valid = false;
     return RT_OK;
@@ -315,9 +341,14 @@ int ensure_wavefront(rt_ctx* ctx, DeviceState& d, uint32_t n_blocks, uint32_t ba
     HIPCHK(ctx, alloc((void**)&w.pxy, P * 4));
     // producers reserve queue space in windows (wavefront.hip): wf_queue_slots is the bound on real entries + padding
     const uint32_t lights = std::max(1u, n_lights);
-    HIPCHK(ctx, alloc((void**)&w.q_ext[0], rt::wf_queue_slots(P, 1) * 4));
-    HIPCHK(ctx, alloc((void**)&w.q_ext[1], rt::wf_queue_slots(P, 1) * 4));
-    HIPCHK(ctx, alloc((void**)&w.q_shadow, rt::wf_queue_slots(P * (size_t)lights, lights) * 4));
+    const size_t ext_slots = rt::wf_queue_slots(P, 1), shadow_slots = rt::wf_queue_slots(P * (size_t)lights, lights);
+    if (ext_slots > 0xFFFFFFFFull || shadow_slots > 0xFFFFFFFFull)
+        return ctx->fail(RT_ERR_INTERNAL, "wavefront queues of %zu / %zu slots exceed 32-bit positions", ext_slots, shadow_slots);
+    HIPCHK(ctx, alloc((void**)&w.q_ext[0], ext_slots * 4));
+    HIPCHK(ctx, alloc((void**)&w.q_ext[1], ext_slots * 4));
+    HIPCHK(ctx, alloc((void**)&w.q_shadow, shadow_slots * 4));
+    w.q_ext_cap = (uint32_t)ext_slots;
+    w.q_shadow_cap = (uint32_t)shadow_slots;
     HIPCHK(ctx, alloc((void**)&w.counters, rt::WF_N_COUNTERS * sizeof(uint32_t)));
     HIPCHK(ctx, alloc((void**)&w.totals, 16 * sizeof(unsigned long long)));
     HIPCHK(ctx, alloc((void**)&w.accum, (size_t)std::max(1u, n_blocks) * 64 * 16));
@@ -337,10 +368,10 @@ int ensure_wavefront(rt_ctx* ctx, DeviceState& d, uint32_t n_blocks, uint32_t ba
 // queue entry and the 32-bit queue positions; the samples are then spread evenly over the batches.
 // RT_WF_BATCH (samples per batch) / RT_WF_TARGET_PATHS override.
 // Largest number of path slots the wavefront pipeline can address: 27-bit path ids in shadow queue entries, 32-bit queue
-// positions with up to 2.5 slots per (path, light).
+// positions with up to 4 slots per (path, light) plus per-wave slack (wf_queue_slots).
 uint64_t wavefront_max_paths(uint32_t n_lights) {
     const uint64_t lights = std::max(1u, n_lights);
-    return std::min<uint64_t>((uint64_t)RT_WF_ID_MASK + 1, (1ull << 30) / lights);
+    return std::min<uint64_t>((uint64_t)RT_WF_ID_MASK + 1, (1ull << 29) / lights);
 }
 
 uint32_t wavefront_batch(uint32_t n_blocks, uint32_t spp, uint32_t n_lights, size_t free_bytes) {
@@ -353,7 +384,7 @@ uint32_t wavefront_batch(uint32_t n_blocks, uint32_t spp, uint32_t n_lights, siz
     uint64_t target_paths = 64ull << 20;
     if (const char* e = std::getenv("RT_WF_TARGET_PATHS")) target_paths = std::max<uint64_t>(1, std::strtoull(e, nullptr, 10));
     const uint64_t lights = std::max(1u, n_lights);
-    const uint64_t bytes_per_path = 8 * 16 + 4 + 2 * 10 + 10 * lights; // path state, vis, pxy, two extension queues, shadow queue (2.5 slots per entry)
+    const uint64_t bytes_per_path = 8 * 16 + 4 + 2 * 16 + 16 * lights; // path state, vis, pxy, two extension queues, shadow queue (4 slots per entry)
     target_paths = std::min<uint64_t>(target_paths, free_bytes / 2 / bytes_per_path);
     target_paths = std::min<uint64_t>(target_paths, wavefront_max_paths(n_lights));
     const uint32_t max_batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(spp, target_paths / per_sample));
@@ -385,6 +416,7 @@ int run_frame(rt_ctx* ctx, DevFrame fr, bool counters, uint32_t world, uint32_t 
     }
     size_t nd = single_tile ? 1 : ctx->devs.size();
     uint32_t total_tiles = fr.tiles_x * fr.tiles_y;
+    bool fallback = false; // the extended mode was asked for its default (queue) pipeline and got the megakernel
     for (size_t j = 0; j < nd; j++) {
         DeviceState& d = ctx->devs[j];
         HIPCHK(ctx, hipSetDevice(d.device));
@@ -408,6 +440,7 @@ int run_frame(rt_ctx* ctx, DevFrame fr, bool counters, uint32_t world, uint32_t 
         const bool wavefront = f.mode == RT_MODE_EXTENDED && !(f.flags & (RT_FLAG_KERNEL_V1 | RT_FLAG_KERNEL_SM)) &&
                                ctx->scene_counts.n_lights <= RT_WF_MAX_LIGHTS &&
                                (uint64_t)f.n_owned_tiles * rt::blocks_per_tile(f.tile_size) * 64u <= wavefront_max_paths(ctx->scene_counts.n_lights);
+        if (f.mode == RT_MODE_EXTENDED && !wavefront && !(f.flags & (RT_FLAG_KERNEL_V1 | RT_FLAG_KERNEL_SM))) fallback = true;
         if (wavefront) {
             const uint32_t n_blocks = f.n_owned_tiles * rt::blocks_per_tile(f.tile_size);
             size_t free_b = 0, total_b = 0;
@@ -474,6 +507,7 @@ int run_frame(rt_ctx* ctx, DevFrame fr, bool counters, uint32_t world, uint32_t 
             cnt[5] += t[2];
             cnt[1] += t[3];
             cnt[2] += t[4];
+            if (t[WF_TOTAL_ERROR] != 0) return ctx->fail(RT_ERR_INTERNAL, "wavefront pipeline: a queue reservation exceeded its allocation (frame discarded)");
             cnt[8] = std::max(cnt[8], t[5]); // diagnostics: stack high-water mark, visits with > 16 / > 24 entries
             cnt[9] += t[6];
             cnt[10] += t[7];
@@ -512,6 +546,7 @@ int run_frame(rt_ctx* ctx, DevFrame fr, bool counters, uint32_t world, uint32_t 
     for (int k = 0; k < 8; k++) ctx->diag[k] = counters ? cnt[8 + k] : 0;
     st.kernel_ms = kernel_ms;
     st.wall_ms = now_ms() - w0;
+    st.flags = fallback ? RT_STAT_MEGAKERNEL_FALLBACK : 0u;
     return RT_OK;
 }
 
@@ -671,6 +706,34 @@ int rt_upload_scene_packed(rt_ctx* ctx, const uint32_t* md, size_t n_u32, const 
                          materials, n_materials);
 }
 
+int rt_upload_textures(rt_ctx* ctx, const rt_texture_info* textures, uint32_t n_textures, const uint8_t* texture_data, size_t n_bytes) {
+    if (!ctx) return RT_ERR_BAD_ARG;
+    if ((n_textures && !textures) || (n_bytes && !texture_data)) return ctx->fail(RT_ERR_BAD_ARG, "rt_upload_textures: null array with non-zero count");
+    for (uint32_t i = 0; i < n_textures; i++)
+        if ((uint64_t)textures[i].offset + textures[i].size > n_bytes)
+            return ctx->fail(RT_ERR_BAD_ARG, "rt_upload_textures: texture %u (offset %u, %u bytes) exceeds the %zu bytes of texture data", i,
+                             textures[i].offset, textures[i].size, n_bytes);
+    // main_cs binds both buffers and reads neither (`_textures`, `_texture_data`, shader/src/lib.rs:34-35): nothing goes to the device
+    ctx->n_textures = n_textures;
+    ctx->texture_bytes = n_bytes;
+    ctx->stats.n_textures = n_textures;
+    ctx->stats.texture_bytes = n_bytes;
+    return RT_OK;
+}
+
+// Development aid (not part of rt_hip.h): make the next scene upload fail before its k-th device array, as an allocation failure would.
+int rt_debug_fail_upload(rt_ctx* ctx, int k) {
+    if (!ctx) return RT_ERR_BAD_ARG;
+    ctx->fail_upload_at = k;
+    return RT_OK;
+}
+
+// Development aids (not part of rt_hip.h): the queue allocation bound and the window rule, host-only arithmetic (tests/test_queue_bound.py).
+unsigned long long rt_debug_queue_slots(unsigned long long max_entries, uint32_t per_lane, unsigned long long waves) {
+    return rt::wf_queue_slots_for((size_t)max_entries, per_lane, (size_t)waves);
+}
+uint32_t rt_debug_pick_window(uint32_t iterations, uint32_t per_lane) { return rt::wf_pick_window(iterations, per_lane); }
+
 int rt_render(rt_ctx* ctx, const rt_render_params* p) {
     if (!ctx) return RT_ERR_BAD_ARG;
     if (!p) return ctx->fail(RT_ERR_BAD_ARG, "rt_render: null params");
@@ -680,6 +743,10 @@ int rt_render(rt_ctx* ctx, const rt_render_params* p) {
     if (p->mode > RT_MODE_EXTENDED) return ctx->fail(RT_ERR_BAD_ARG, "rt_render: mode %u not supported", p->mode);
     if (p->mode == RT_MODE_EXTENDED && (p->spp == 0 || p->spp > 65536u))
         return ctx->fail(RT_ERR_BAD_ARG, "rt_render: spp %u out of range", p->spp);
+    // bounce depths travel in 8 bits in the reference (pack_flags, shared/src/lib.rs:1154-1179); modes 0/1 mask as the
+    // reference does, the extended mode refuses what it cannot represent rather than looping 2^32 times
+    if (p->mode == RT_MODE_EXTENDED && p->max_bounces > RT_MAX_BOUNCES)
+        return ctx->fail(RT_ERR_BAD_ARG, "rt_render: max_bounces %u > %u", p->max_bounces, RT_MAX_BOUNCES);
     uint32_t world = p->tile_world ? p->tile_world : 1, rank = p->tile_rank;
     if (rank >= world) return ctx->fail(RT_ERR_BAD_ARG, "rt_render: tile_rank %u >= tile_world %u", rank, world);
     DevFrame fr{};

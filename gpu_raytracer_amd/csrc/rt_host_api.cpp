@@ -224,6 +224,23 @@ int rt_host_write_exr(const char* path, const float* rgb32f, uint32_t width, uin
     return write_exr(path, rgb32f, width, height) ? RT_OK : RT_HOST_ERR_IO;
 }
 
+float rt_host_branchless_float_if_nonnan(int condition, float if_true, float if_false) { return branchless::float_if_nonnan(condition != 0, if_true, if_false); }
+float rt_host_branchless_float_if(int condition, float if_true, float if_false, int* valid) {
+    const branchless::FloatIf r = branchless::float_if(condition != 0, if_true, if_false);
+    if (valid) *valid = r.valid ? 1 : 0;
+    return r.value;
+}
+uint32_t rt_host_branchless_u32_if(int condition, uint32_t if_true, uint32_t if_false) { return branchless::u32_if(condition != 0, if_true, if_false); }
+
+int rt_host_bvh_triangle(const rt_triangle* triangle, const rt_vertex* vertices, uint32_t n_vertices, float centroid[3], rt_aabb* box) {
+    if (!triangle || !vertices) return RT_ERR_BAD_ARG;
+    if (triangle->v0_index >= n_vertices || triangle->v1_index >= n_vertices || triangle->v2_index >= n_vertices) return RT_ERR_BAD_ARG;
+    const BvhTriangle b = bvh_triangle::new_(*triangle, 0);
+    if (centroid) bvh_triangle::centroid(b, vertices, centroid);
+    if (box) *box = bvh_triangle::aabb(b, vertices);
+    return RT_OK;
+}
+
 void rt_host_progressive_timing(double out[7]) {
     for (int i = 0; i < 7; i++) out[i] = g_timing[i];
 }

@@ -44,8 +44,10 @@ struct WfBuffers {
     uint32_t* q_ext[2];  // path ids to extend (double buffered)
     uint32_t* q_shadow;  // path id | light << 27
     uint32_t* counters;  // WfCounter
-    unsigned long long* totals; // [0] camera [1] continuation [2] shadow segments, [3] node visits, [4] triangle tests
+    unsigned long long* totals; // [0] camera [1] continuation [2] shadow segments, [3] node visits, [4] triangle tests, [15] error word
     float4* accum;       // per owned pixel slot: running sum over samples (in sample order)
+    uint32_t q_ext_cap;  // slots allocated for each extension queue / the shadow queue: a window reservation that would
+    uint32_t q_shadow_cap; // end beyond it raises totals[WF_TOTAL_ERROR] instead of writing (window_reserve)
     uint32_t* stack_ovf; // global overflow part of the traversal stacks: [persistent wave][entry][lane]
     uint32_t ovf_entries; // entries per lane in it
     uint32_t n_blocks;   // 8x8 pixel blocks owned by this device
@@ -53,12 +55,15 @@ struct WfBuffers {
     uint32_t capacity;   // path slots
 };
 
+#define WF_TOTAL_ERROR 15 /* totals[] slot: non-zero = a queue reservation did not fit; every later stage kernel of the frame returns at once */
 #define RT_WF_LDS_STACK 16 /* traversal stack entries kept in LDS by the persistent kernels; deeper ones overflow to HBM */
 #define RT_WF_MAX_LIGHTS 32u /* visibility is one bit per light in a 32-bit word */
 #define RT_WF_ID_MASK 0x07FFFFFFu
 
 uint32_t wf_shading_blocks(); // grid size (256-thread blocks) of the generate / shade / finish kernels
 size_t wf_queue_slots(size_t max_entries, uint32_t per_lane); // allocation bound of a queue holding up to max_entries real entries, written with up to per_lane entries per lane and iteration
+size_t wf_queue_slots_for(size_t max_entries, uint32_t per_lane, size_t producing_waves); // the same for a given number of producing waves (host-only arithmetic, unit-tested)
+uint32_t wf_pick_window(uint32_t iterations, uint32_t per_lane); // the reservation window a producing wave uses (host copy of the device rule, unit-tested)
 uint32_t wf_persistent_waves(); // grid size (in 64-lane blocks) of the persistent traversal kernels on the current device
 hipError_t wf_generate(const DevScene& sc, const DevFrame& fr, const WfBuffers& wb, uint32_t first_sample, uint32_t n_samples, hipStream_t s);
 hipError_t wf_bounce(const DevScene& sc, const DevFrame& fr, const WfBuffers& wb, uint32_t iteration, bool counters, hipStream_t s);

@@ -77,7 +77,7 @@ __host__ __device__ inline uint32_t wf_min_window(uint32_t per_lane) { // >= 2 x
     return w;
 }
 // iters: iterations a producing wave will run at most; per_lane: entries a lane can emit per iteration
-__device__ __forceinline__ uint32_t pick_window(uint32_t iters, uint32_t per_lane) {
+__host__ __device__ inline uint32_t pick_window(uint32_t iters, uint32_t per_lane) {
     const uint32_t most = iters * WAVE * per_lane;
     uint32_t w = wf_min_window(per_lane);
     while (w < most / 4u && w < RT_WF_WINDOW_MAX) w <<= 1;
@@ -91,14 +91,23 @@ __device__ __forceinline__ void window_close(uint32_t* __restrict__ queue, OutWi
     for (uint32_t i = w.next + (threadIdx.x & 63u); i < w.end; i += WAVE) queue[i] = WF_SENTINEL;
     w.next = w.end;
 }
-// returns the first slot for this lane; `mine` entries per lane, `incl` = inclusive prefix of `mine` over the wave
+#define WF_NO_SLOT 0xFFFFFFFFu
+// returns the first slot for this lane; `mine` entries per lane, `incl` = inclusive prefix of `mine` over the wave.
+// A reservation that would end beyond the queue's allocation (`capacity` slots) is not used: the error word is raised,
+// the caller gets WF_NO_SLOT and must not write, every later stage kernel of the frame returns at once and the host
+// reports RT_ERR_INTERNAL (the allocation bound wf_queue_slots is derived below; this is the belt to its braces).
 __device__ __forceinline__ uint32_t window_reserve(uint32_t* __restrict__ queue, uint32_t* __restrict__ counter, OutWindow& w, uint32_t window,
-                                                  uint32_t mine, uint32_t incl, uint32_t total) {
+                                                  uint32_t mine, uint32_t incl, uint32_t total, uint32_t capacity, unsigned long long* __restrict__ error) {
     if (w.next + total > w.end) {
         window_close(queue, w);
         uint32_t base = 0;
         if ((threadIdx.x & 63u) == 0) base = atomicAdd(counter, window); // total <= window / 2 by construction (wf_min_window)
         base = __shfl(base, 0, WAVE);
+        if (base > capacity || window > capacity - base) { // wave-uniform
+            if ((threadIdx.x & 63u) == 0) atomicOr(error, 1ull);
+            w.next = w.end = 0u;
+            return WF_NO_SLOT;
+        }
         w.next = base;
         w.end = base + window;
     }
@@ -158,8 +167,8 @@ __global__ __launch_bounds__(256) void k_wf_generate(DevFrame fr, rt::WfBuffers 
         const uint32_t mine = px.valid ? 1u : 0u;
         const uint32_t incl = wave_incl_scan(mine), total = __shfl(incl, WAVE - 1, WAVE);
         if (total) {
-            const uint32_t at = window_reserve(wb.q_ext[0], &wb.counters[rt::WF_EXT_COUNT], win, window, mine, incl, total);
-            if (mine) wb.q_ext[0][at] = p;
+            const uint32_t at = window_reserve(wb.q_ext[0], &wb.counters[rt::WF_EXT_COUNT], win, window, mine, incl, total, wb.q_ext_cap, &wb.totals[WF_TOTAL_ERROR]);
+            if (mine && at != WF_NO_SLOT) wb.q_ext[0][at] = p;
             real += mine;
         }
     }
@@ -175,6 +184,7 @@ template <bool COUNT, bool ANY>
 __global__ __launch_bounds__(WAVE, RT_WF_MIN_WAVES) void k_wf_trace(DevScene sc, rt::WfBuffers wb, const uint32_t* __restrict__ queue, uint32_t count_slot,
                                                    uint32_t cursor_slot, uint32_t window_slot) {
     extern __shared__ uint32_t s_stack[];
+    if (wb.totals[WF_TOTAL_ERROR] != 0ull) return; // an earlier stage overran a queue: its contents are not to be trusted
     const uint32_t lane = threadIdx.x;
     uint32_t* __restrict__ stack = s_stack + lane;
     uint32_t* __restrict__ ovf = wb.stack_ovf + (size_t)blockIdx.x * wb.ovf_entries * WAVE + lane;
@@ -379,6 +389,7 @@ __device__ __forceinline__ void wf_end_path(const rt::WfBuffers& wb, uint32_t id
 
 __global__ __launch_bounds__(256, RT_WF_SHADE_WAVES) void k_wf_shade(DevScene sc, DevFrame fr, rt::WfBuffers wb, const uint32_t* __restrict__ queue) {
     __shared__ DevLight s_lights[RT_WF_MAX_LIGHTS];
+    if (wb.totals[WF_TOTAL_ERROR] != 0ull) return;
     stage_lights(s_lights, sc);
     const uint32_t count = wb.counters[rt::WF_EXT_COUNT];
     const bool shadows = (fr.flags & 2u) == 0;
@@ -438,10 +449,10 @@ __global__ __launch_bounds__(256, RT_WF_SHADE_WAVES) void k_wf_shade(DevScene sc
             uint32_t total = 0;
             for (uint32_t li = 0; li < sc.n_lights; li++) total += (uint32_t)__popcll(__ballot((mask >> li) & 1u));
             if (total) {
-                uint32_t at = window_reserve(wb.q_shadow, &wb.counters[rt::WF_SHADOW_COUNT], win, window, 0u, 0u, total);
+                uint32_t at = window_reserve(wb.q_shadow, &wb.counters[rt::WF_SHADOW_COUNT], win, window, 0u, 0u, total, wb.q_shadow_cap, &wb.totals[WF_TOTAL_ERROR]);
                 n_shadow += (uint32_t)__popc(mask);
                 const unsigned long long below = (1ull << (threadIdx.x & 63u)) - 1ull;
-                for (uint32_t li = 0; li < sc.n_lights; li++) {
+                for (uint32_t li = 0; at != WF_NO_SLOT && li < sc.n_lights; li++) {
                     const bool want = (mask >> li) & 1u;
                     const unsigned long long b = __ballot(want);
                     if (want) wb.q_shadow[at + (uint32_t)__popcll(b & below)] = id | (li << 27);
@@ -452,9 +463,9 @@ __global__ __launch_bounds__(256, RT_WF_SHADE_WAVES) void k_wf_shade(DevScene sc
             const uint32_t mine = (uint32_t)__popc(mask);
             const uint32_t incl = wave_incl_scan(mine), total = __shfl(incl, WAVE - 1, WAVE);
             if (total) {
-                uint32_t at = window_reserve(wb.q_shadow, &wb.counters[rt::WF_SHADOW_COUNT], win, window, mine, incl, total);
+                uint32_t at = window_reserve(wb.q_shadow, &wb.counters[rt::WF_SHADOW_COUNT], win, window, mine, incl, total, wb.q_shadow_cap, &wb.totals[WF_TOTAL_ERROR]);
                 n_shadow += mine;
-                while (mask) {
+                while (mask && at != WF_NO_SLOT) {
                     const uint32_t li = (uint32_t)__ffs((int)mask) - 1u;
                     mask &= mask - 1u;
                     wb.q_shadow[at++] = id | (li << 27);
@@ -474,6 +485,7 @@ __global__ __launch_bounds__(256, RT_WF_SHADE_WAVES) void k_wf_shade(DevScene sc
 __global__ __launch_bounds__(256, RT_WF_SHADE_WAVES) void k_wf_finish(DevScene sc, DevFrame fr, rt::WfBuffers wb, const uint32_t* __restrict__ queue,
                                                   uint32_t* __restrict__ next_queue) {
     __shared__ DevLight s_lights[RT_WF_MAX_LIGHTS];
+    if (wb.totals[WF_TOTAL_ERROR] != 0ull) return;
     stage_lights(s_lights, sc);
     const uint32_t count = wb.counters[rt::WF_EXT_COUNT];
     const bool shadows = (fr.flags & 2u) == 0;
@@ -597,8 +609,8 @@ __global__ __launch_bounds__(256, RT_WF_SHADE_WAVES) void k_wf_finish(DevScene s
         const uint32_t mine = cont ? 1u : 0u;
         const uint32_t incl = wave_incl_scan(mine), total = __shfl(incl, WAVE - 1, WAVE);
         if (total) {
-            const uint32_t at = window_reserve(next_queue, &wb.counters[rt::WF_EXT_NEXT], win, window, mine, incl, total);
-            if (cont) next_queue[at] = id;
+            const uint32_t at = window_reserve(next_queue, &wb.counters[rt::WF_EXT_NEXT], win, window, mine, incl, total, wb.q_ext_cap, &wb.totals[WF_TOTAL_ERROR]);
+            if (cont && at != WF_NO_SLOT) next_queue[at] = id;
             n_cont += mine;
         }
     }
@@ -668,14 +680,21 @@ uint32_t wf_shading_blocks() {
     }();
     return (uint32_t)(cu_count() * per_cu);
 }
-// Slots a queue can take up: a wave's reservations hold at least half real entries each (a request is at most half
-// the minimum window), plus one window it may leave unused at the end: <= 2 x real + waves x W, and
-// W <= max(minimum, half of what the wave can emit), so summed over the producing waves
-// <= 2.5 x max_entries + waves x (minimum window + one iteration's worth).
-size_t wf_queue_slots(size_t max_entries, uint32_t per_lane) {
-    const size_t waves = (size_t)wf_shading_blocks() * 4;
-    return max_entries * 5 / 2 + (waves + 1) * ((size_t)wf_min_window(per_lane) + 64u * per_lane) + RT_WF_WINDOW_MAX;
+// Slots a queue can take up.  A producing wave asks for at most 64 x per_lane entries at a time and a window is at
+// least twice that (wf_min_window), so a window that is closed holds more than half real entries: closed windows take
+// <= 2 x real entries.  On top comes the one window each wave leaves partly unused at the end.  Its size W is
+// pick_window(iterations, per_lane) <= max(minimum, half of what the wave could emit), and "what the wave could emit"
+// is derived from the length of the queue it CONSUMES, padding included.  With C the allocation of the consumed queue,
+// the last windows of all waves sum to <= C x per_lane / 2 + waves x (minimum + one iteration).  For an extension
+// queue (per_lane 1, consuming an extension queue of the same allocation): C <= 2 P + C / 2 + slack, i.e. C <= 4 P +
+// slack; for the shadow queue (per_lane L, consuming an extension queue): <= 2 P L + (4 P) L / 2 = 4 P L.  Hence 4 x.
+// (Round 1 allocated 2.5 x on an argument that ignored the padding of the consumed queue; the worst case worked out
+// to 2.48 x - a 1 % margin.  window_reserve now also checks every reservation against the allocation.)
+size_t wf_queue_slots_for(size_t max_entries, uint32_t per_lane, size_t waves) {
+    return max_entries * 4 + (waves + 1) * 2 * ((size_t)wf_min_window(per_lane) + 64u * per_lane) + RT_WF_WINDOW_MAX;
 }
+size_t wf_queue_slots(size_t max_entries, uint32_t per_lane) { return wf_queue_slots_for(max_entries, per_lane, (size_t)wf_shading_blocks() * 4); }
+uint32_t wf_pick_window(uint32_t iters, uint32_t per_lane) { return pick_window(iters, per_lane); }
 uint32_t wf_persistent_waves() { return (uint32_t)(cu_count() * RT_WF_WAVES_PER_CU); }
 
 hipError_t wf_generate(const DevScene&, const DevFrame& fr, const WfBuffers& wb, uint32_t first_sample, uint32_t n_samples, hipStream_t s) {

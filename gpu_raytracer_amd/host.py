@@ -10,7 +10,8 @@ from . import types as T
 
 HOST_SYMBOLS = ["rt_host_material_new", "rt_host_light_new", "rt_host_push_constants_new", "rt_host_tile_count",
                 "rt_host_tiles_per_frame", "rt_host_default_scene", "rt_host_bvh_build", "rt_host_pack_scene_metadata",
-                "rt_host_render_progressive"]
+                "rt_host_render_progressive", "rt_host_branchless_float_if_nonnan", "rt_host_branchless_float_if",
+                "rt_host_branchless_u32_if", "rt_host_bvh_triangle"]
 
 
 def _lib():
@@ -56,6 +57,41 @@ def push_constants_new(resolution, camera, triangle_count, material_count, tile_
                                       C.c_uint32(triangles_per_buffer), _p(off), C.c_uint32(channel), C.c_uint32(mode),
                                       C.c_uint32(cur_bounce), C.c_uint32(max_bounce), C.c_uint32(frame_seed))
     return out[0]
+
+
+def branchless_float_if_nonnan(condition, if_true, if_false):
+    lib = _lib()
+    lib.rt_host_branchless_float_if_nonnan.restype = C.c_float
+    return lib.rt_host_branchless_float_if_nonnan(C.c_int(bool(condition)), C.c_float(if_true), C.c_float(if_false))
+
+
+def branchless_float_if(condition, if_true, if_false):
+    """branchless_float_if!(cond, a, b) -> (value, valid)  (shared/src/lib.rs:1295-1313)"""
+    lib = _lib()
+    lib.rt_host_branchless_float_if.restype = C.c_float
+    valid = C.c_int(0)
+    v = lib.rt_host_branchless_float_if(C.c_int(bool(condition)), C.c_float(if_true), C.c_float(if_false), C.byref(valid))
+    return v, bool(valid.value)
+
+
+def branchless_u32_if(condition, if_true, if_false):
+    lib = _lib()
+    lib.rt_host_branchless_u32_if.restype = C.c_uint32
+    return lib.rt_host_branchless_u32_if(C.c_int(bool(condition)), C.c_uint32(if_true), C.c_uint32(if_false))
+
+
+def bvh_triangle(triangle, vertices):
+    """BvhTriangle::centroid + BvhTriangleWithVertices::aabb (src/bvh.rs:27-55) -> (centroid[3], aabb record)"""
+    lib = _lib()
+    lib.rt_host_bvh_triangle.restype = C.c_int
+    tri = np.ascontiguousarray(triangle, dtype=T.TRIANGLE).reshape(())
+    ve = np.ascontiguousarray(vertices, dtype=T.VERTEX)
+    c = np.zeros(3, np.float32)
+    box = np.zeros((), dtype=T.AABB)
+    rc = lib.rt_host_bvh_triangle(C.c_void_p(tri.ctypes.data), _p(ve), C.c_uint32(len(ve)), _p(c), C.c_void_p(box.ctypes.data))
+    if rc != 0:
+        raise ValueError(f"rt_host_bvh_triangle failed: {rc}")
+    return c, box
 
 
 def tile_count(width, height, tile_size=T.TILE_SIZE):

@@ -65,8 +65,11 @@ STATS = np.dtype([
     ("node_visits", np.uint64), ("tri_tests", np.uint64),
     ("kernel_ms", np.float64), ("wall_ms", np.float64),
     ("node_bytes", np.uint64), ("tri_bytes", np.uint64), ("scene_bytes", np.uint64),
-    ("bvh_nodes", u32), ("bvh_depth", u32), ("n_devices", u32), ("_pad", u32),
+    ("bvh_nodes", u32), ("bvh_depth", u32), ("n_devices", u32), ("flags", u32),
+    ("texture_bytes", np.uint64), ("n_textures", u32), ("_pad", u32),
 ])
+STAT_MEGAKERNEL_FALLBACK = 1
+MAX_BOUNCES = 255
 
 EXPECTED_SIZES = {
     "CAMERA": 40, "MATERIAL": 128, "LIGHT": 52, "TEXTURE_INFO": 32, "SPHERE": 20, "VERTEX": 12,

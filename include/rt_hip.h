@@ -67,7 +67,8 @@ typedef struct rt_render_params {
     uint32_t width, height;
     uint32_t spp;         /* samples per pixel; modes 0/1 have no spp in the reference: they trace   */
                           /* the single pixel-centre ray and ignore this field                       */
-    uint32_t max_bounces; /* mode 1: max_bounce_depth of pack_flags; mode 2: continuation segments   */
+    uint32_t max_bounces; /* mode 1: max_bounce_depth of pack_flags; mode 2: continuation segments,  */
+                          /* at most RT_MAX_BOUNCES (RT_ERR_BAD_ARG beyond)                          */
     uint32_t mode;        /* RT_MODE_*                                                               */
     uint32_t frame_seed;  /* PushConstants::frame_seed (shared/src/lib.rs:226)                       */
     uint32_t tile_size;   /* 0 = RT_TILE_SIZE (128). Tile grid = TileHelper::calculate_tile_count    */
@@ -93,8 +94,18 @@ typedef struct rt_stats {
     uint32_t bvh_nodes;    /* nodes in the device BVH                                                 */
     uint32_t bvh_depth;    /* its depth                                                               */
     uint32_t n_devices;
+    uint32_t flags;        /* RT_STAT_* of the last render                                            */
+    uint64_t texture_bytes; /* bytes of texture data last handed to rt_upload_textures (never sampled) */
+    uint32_t n_textures;   /* TextureInfo records last handed to rt_upload_textures                   */
     uint32_t _pad;
 } rt_stats;
+
+/* rt_stats.flags */
+#define RT_STAT_MEGAKERNEL_FALLBACK 1u /* extended mode: the frame did not fit the queue pipeline (more than 32 lights: one
+                                          visibility bit per light; or a device share beyond the addressable path slots) and
+                                          was rendered by the state-machine megakernel: same image, about 3x slower */
+
+#define RT_MAX_BOUNCES 255u /* extended mode: bounce depths travel in 8 bits, as in pack_flags (shared/src/lib.rs:1154-1179) */
 
 /* Create a context on `n_devices` HIP devices (ids in device_ids; NULL = device 0..n-1).
  * Replaces RenderState::new's adapter/device acquisition (src/renderer.rs:93-125).
@@ -126,6 +137,14 @@ int rt_upload_scene_packed(rt_ctx* ctx,
                            const rt_triangle* const tri_buffers[3], const uint32_t tri_counts[3],
                            uint32_t triangles_per_buffer,
                            const rt_material* materials, uint32_t n_materials);
+
+/* Hand over what bindings 6-7 carry (src/renderer.rs:250-341): the TextureInfo array of
+ * BufferManager::update_textures (src/buffers.rs:381-419) and the texture bytes of update_texture_data
+ * (src/buffers.rs:422-470, which packs them four to a u32).  main_cs binds both and reads neither
+ * (shader/src/lib.rs:34-35), so they are validated (every texture inside the data) and recorded in rt_stats, nothing
+ * else: a host that keeps its update_* call sequence maps one to one.  Independent of rt_upload_scene*. */
+int rt_upload_textures(rt_ctx* ctx, const rt_texture_info* textures, uint32_t n_textures,
+                       const uint8_t* texture_data, size_t n_bytes);
 
 /* Render a whole frame (all tiles of this context's share, all three colour channels in
  * one pass).  Replaces ComputeRenderer::run_compute's tile x channel loop

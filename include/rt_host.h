@@ -34,6 +34,16 @@ void rt_host_camera_move(rt_camera* camera, float forward, float right);
 void rt_host_tile_count(uint32_t width, uint32_t height, uint32_t tile_size, uint32_t* tiles_x, uint32_t* tiles_y);
 uint32_t rt_host_tiles_per_frame(uint32_t total_tiles);
 
+/* branchless_float_if! / branchless_u32_if! (shared/src/lib.rs:1293-1326; never used by the shader, pinned by the
+ * reference's unit tests :1333-1365): the `@nonnan` arm, the NaN-aware arm (returns the value, *valid = the macro's
+ * second tuple element) and the integer select. */
+float rt_host_branchless_float_if_nonnan(int condition, float if_true, float if_false);
+float rt_host_branchless_float_if(int condition, float if_true, float if_false, int* valid);
+uint32_t rt_host_branchless_u32_if(int condition, uint32_t if_true, uint32_t if_false);
+
+/* BvhTriangle::centroid (src/bvh.rs:27-37) and BvhTriangleWithVertices::aabb (src/bvh.rs:47-55) of one triangle. */
+int rt_host_bvh_triangle(const rt_triangle* triangle, const rt_vertex* vertices, uint32_t n_vertices, float centroid[3], rt_aabb* box);
+
 /* SceneBuilder::build_default_scene (shared/src/lib.rs:1242-1286) + Camera::new.  Arrays must hold
  * 6 spheres, 2 triangles, 6 vertices, 4 materials, 1 light; returns 0, or -1 if a capacity is too small. */
 int rt_host_default_scene(rt_sphere* spheres, uint32_t* n_spheres, rt_triangle* triangles, uint32_t* n_triangles, rt_vertex* vertices,

@@ -33,7 +33,9 @@ class Counters(C.Structure):
 
 
 def build(force=False):
-    if force or not os.path.exists(_LIB_PATH):
+    srcs = [os.path.join(_HERE, f) for f in ("rt_oracle.cpp", "rt_oracle_bvh.cpp", "rt_oracle.h")]
+    stale = os.path.exists(_LIB_PATH) and any(os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
+    if force or stale or not os.path.exists(_LIB_PATH):
         subprocess.check_call(["make", "-C", _HERE] + (["-B"] if force else []))
     return _LIB_PATH
 
@@ -49,6 +51,7 @@ def lib():
         _lib.oracle_dispatch.restype = C.c_int
         _lib.oracle_render_frame.restype = C.c_int
         _lib.oracle_render_extended.restype = C.c_int
+        _lib.oracle_render_extended_region.restype = C.c_int
         _lib.oracle_build_bvh.restype = C.c_int
         _lib.oracle_f32_to_f16.restype = C.c_uint16
         _lib.oracle_f32_to_f16.argtypes = [C.c_float]
@@ -166,15 +169,18 @@ def render_frame(packed, width, height, camera=None, mode=0, cur_bounce=0, max_b
 EXT_NO_SHADOWS = 2
 
 
-def render_extended(packed, width, height, spp, max_bounces, camera=None, frame_seed=0, flags=0, threads=None):
-    """Extended mode (the build's own path tracer, CPU statement).  Returns dict(rgb, segments, counters)."""
+def render_extended(packed, width, height, spp, max_bounces, camera=None, frame_seed=0, flags=0, threads=None, region=None):
+    """Extended mode (the build's own path tracer, CPU statement).  Returns dict(rgb, segments, counters).
+    region = (x0, y0, w, h): only that rectangle of the width x height frame (rgb has the rectangle's shape)."""
     threads = threads or os.cpu_count() or 1
     pc = np.ascontiguousarray(packed.push_constants(width, height, camera, 0, 1, 0, max_bounces & 0xFF, frame_seed))
-    rgb = np.zeros((height, width, 3), np.float32)
+    x0, y0, rw, rh = region if region is not None else (0, 0, width, height)
+    rgb = np.zeros((rh, rw, 3), np.float32)
     seg = (C.c_uint64 * 4)()
     c = Counters()
-    rc = lib().oracle_render_extended(C.byref(packed.bindings), _ptr(pc), C.c_uint32(spp), C.c_uint32(max_bounces),
-                                      C.c_uint32(flags), C.c_int(threads), _ptr(rgb), seg, C.byref(c))
+    rc = lib().oracle_render_extended_region(C.byref(packed.bindings), _ptr(pc), C.c_uint32(spp), C.c_uint32(max_bounces),
+                                             C.c_uint32(flags), C.c_int(threads), C.c_uint32(x0), C.c_uint32(y0), C.c_uint32(rw),
+                                             C.c_uint32(rh), _ptr(rgb), seg, C.byref(c))
     if rc != 0:
         raise RuntimeError(f"oracle_render_extended failed: {rc}")
     return {"rgb": rgb, "counters": c.as_dict(),

@@ -1016,12 +1016,14 @@ int oracle_render_frame(const oracle_bindings* b, const rt_push_constants* base_
     return 0;
 }
 
-int oracle_render_extended(const oracle_bindings* b, const rt_push_constants* base_pc, uint32_t spp, uint32_t max_bounces,
-                           uint32_t flags, int threads, float* rgb32f, uint64_t* segments, oracle_counters* counters) {
+int oracle_render_extended_region(const oracle_bindings* b, const rt_push_constants* base_pc, uint32_t spp, uint32_t max_bounces,
+                                  uint32_t flags, int threads, uint32_t x0, uint32_t y0, uint32_t rw, uint32_t rh, float* rgb32f,
+                                  uint64_t* segments, oracle_counters* counters) {
     if (!b || !base_pc || !rgb32f || spp == 0) return -1;
     uint32_t width = f32_as_u32(base_pc->resolution[0]);
     uint32_t height = f32_as_u32(base_pc->resolution[1]);
     if (width == 0 || height == 0) return -1;
+    if (x0 > width || y0 > height || rw > width - x0 || rh > height - y0) return -1;
     if (threads < 1) threads = 1;
     rt_push_constants pc = *base_pc;
     pc.packed_flags = (base_pc->packed_flags & 0x00FFFFFFu) | (1u << 24);
@@ -1036,12 +1038,13 @@ int oracle_render_extended(const oracle_bindings* b, const rt_push_constants* ba
         ExtCounts& ec = per_thread_ec[(size_t)tid];
         for (;;) {
             uint32_t row = next.fetch_add(1);
-            if (row >= height) break;
-            for (uint32_t x = 0; x < width; x++) {
+            if (row >= rh) break;
+            for (uint32_t x = 0; x < rw; x++) {
+                // a pixel's samples depend only on its own coordinates in the FULL frame (pixel seed, lib.rs:103-105)
                 V3 sum = v3(0, 0, 0);
-                for (uint32_t s = 0; s < spp; s++) sum = sum + ek.trace_path(x, row, s, spp, ec);
+                for (uint32_t s = 0; s < spp; s++) sum = sum + ek.trace_path(x0 + x, y0 + row, s, spp, ec);
                 float n = (float)spp;
-                size_t pix = (size_t)row * width + x;
+                size_t pix = (size_t)row * rw + x;
                 rgb32f[pix * 3 + 0] = sum.x / n;
                 rgb32f[pix * 3 + 1] = sum.y / n;
                 rgb32f[pix * 3 + 2] = sum.z / n;
@@ -1063,6 +1066,13 @@ int oracle_render_extended(const oracle_bindings* b, const rt_push_constants* ba
         }
     }
     return 0;
+}
+
+int oracle_render_extended(const oracle_bindings* b, const rt_push_constants* base_pc, uint32_t spp, uint32_t max_bounces,
+                           uint32_t flags, int threads, float* rgb32f, uint64_t* segments, oracle_counters* counters) {
+    if (!base_pc) return -1;
+    return oracle_render_extended_region(b, base_pc, spp, max_bounces, flags, threads, 0, 0, f32_as_u32(base_pc->resolution[0]),
+                                         f32_as_u32(base_pc->resolution[1]), rgb32f, segments, counters);
 }
 
 } // extern "C"

@@ -82,6 +82,13 @@ int oracle_render_frame(const oracle_bindings* b, const rt_push_constants* base_
 int oracle_render_extended(const oracle_bindings* b, const rt_push_constants* base_pc,
                            uint32_t spp, uint32_t max_bounces, uint32_t flags, int threads,
                            float* rgb32f, uint64_t* segments, oracle_counters* counters);
+/* The same for the pixel rectangle [x0, x0+rw) x [y0, y0+rh) of the frame whose size base_pc names: rgb32f holds rw*rh*3
+ * floats.  A pixel's samples depend only on its coordinates in the full frame, so a crop of a 3840x2160 frame can be
+ * checked without rendering the whole of it on the CPU. */
+int oracle_render_extended_region(const oracle_bindings* b, const rt_push_constants* base_pc,
+                                  uint32_t spp, uint32_t max_bounces, uint32_t flags, int threads,
+                                  uint32_t x0, uint32_t y0, uint32_t rw, uint32_t rh,
+                                  float* rgb32f, uint64_t* segments, oracle_counters* counters);
 
 /* Restatement of BvhBuilder::build (src/bvh.rs:104-122): empty scene -> one empty
  * leaf (:105-114); > 100,000 triangles -> chunked mesh-order leaves + bottom-up

@@ -1,4 +1,4 @@
-"""Turn a gpurun_out/prof_<tag>/ directory (scripts/profile_r01.sh) into the committed summaries under profiles/.
+"""Turn a gpurun_out/prof_<tag>/ directory (scripts/profile_r02.sh) into the committed summaries under profiles/.
 
   python scripts/summarize_profile.py gpurun_out/prof_X profiles/NAME --frames N [--workload KEY] [--match k_wf_]
 
@@ -33,7 +33,7 @@ summary = {"frames": frames, "kernels": {kname(r["Name"]): {"calls": int(r["Call
 summary["kernel_ms_per_frame"] = sum(v["total_ms_per_frame"] for v in summary["kernels"].values())
 pmc = {}
 by_kernel = collections.defaultdict(dict)
-for d in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq"):
+for d in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq", "pmc_sq2", "pmc_sq3"):
     fs = glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv"))
     if not fs:
         continue
@@ -58,9 +58,23 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
     rd, wr = pmc["FETCH_SIZE"] * 1024, pmc["WRITE_SIZE"] * 1024
     summary["hbm_bytes_per_frame"] = {"read_x1": rd, "read_x2_gfx950_corrected": 2 * rd, "write": wr, "traffic": 2 * rd + wr}
     if key:
+        # the entry bench.py reads: tied to the kernel sources it was measured on (bench.kernel_source_sha16)
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        entry = {"traffic": 2 * rd + wr, "source_sha16": bench.kernel_source_sha16(), "profile": os.path.basename(out) + "_pmc.json",
+                 "kernel_ms_per_frame": summary["kernel_ms_per_frame"]}
+        dom = max(summary["kernels"].items(), key=lambda kv: kv[1]["total_ms_per_frame"])
+        dk = by_kernel.get(dom[0], {})
+        entry["dominant_kernel"] = {"name": dom[0], "ms_per_frame": dom[1]["total_ms_per_frame"], "share_of_frame": dom[1]["total_ms_per_frame"] / summary["kernel_ms_per_frame"],
+                                    "hbm_bytes_per_frame": dk.get("hbm_bytes"), "hbm_GBps": dk.get("hbm_GBps"),
+                                    "hbm_frac_of_8TBps": (dk.get("hbm_GBps") or 0) / 8000.0 or None}
+        if "SQ_ACTIVE_INST_VALU" in pmc:  # quad-cycles summed over the chip's 1024 SIMDs; 2.4 GHz
+            entry["valu_busy"] = 4 * pmc["SQ_ACTIVE_INST_VALU"] / (summary["kernel_ms_per_frame"] * 1e-3 * 2.4e9 * 1024)
+            if "SQ_ACTIVE_INST_VALU" in dk:
+                entry["dominant_kernel"]["valu_busy"] = 4 * dk["SQ_ACTIVE_INST_VALU"] / (dom[1]["total_ms_per_frame"] * 1e-3 * 2.4e9 * 1024)
         tp = os.path.join(os.path.dirname(out), "traffic.json")
         t = json.load(open(tp)) if os.path.exists(tp) else {}
-        t[key] = 2 * rd + wr
+        t[key] = entry
         json.dump(t, open(tp, "w"), indent=1, sort_keys=True)
 if "TCC_HIT_sum" in pmc:
     summary["l2_hit_rate"] = pmc["TCC_HIT_sum"] / (pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"])

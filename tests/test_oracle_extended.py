@@ -117,3 +117,20 @@ def test_fast_traversal_flavour_gives_the_same_images(oracle_mod):
         np.testing.assert_array_equal(b1["rgb"].view(np.uint32), d["rgb"].view(np.uint32))
         np.testing.assert_array_equal(b1["prim"], d["prim"])
         assert d["counters"]["tri_tests"] < b1["counters"]["tri_tests"]
+
+
+def test_extended_region_equals_crop_of_the_frame(oracle_mod):
+    """oracle_render_extended_region: a rectangle of a frame is that frame's crop (a pixel's samples depend only on its
+    coordinates in the full frame), segment counts add up over a partition of the frame."""
+    p = oracle_mod.PackedScene(scenes.cornell12())
+    w, h, spp, bounces = 61, 37, 3, 2
+    full = oracle_mod.render_extended(p, w, h, spp, bounces, frame_seed=9)
+    total = {k: 0 for k in full["segments"]}
+    for (x0, y0, rw, rh) in ((0, 0, 20, 37), (20, 0, 41, 10), (20, 10, 41, 27)):
+        part = oracle_mod.render_extended(p, w, h, spp, bounces, frame_seed=9, region=(x0, y0, rw, rh))
+        np.testing.assert_array_equal(part["rgb"].view(np.uint32), full["rgb"][y0:y0 + rh, x0:x0 + rw].view(np.uint32))
+        for k in total:
+            total[k] += part["segments"][k]
+    assert total == full["segments"]
+    with pytest.raises(RuntimeError):
+        oracle_mod.render_extended(p, w, h, spp, bounces, region=(50, 0, 20, 5))
