@@ -62,6 +62,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default=None, help="resolution of the bounded CPU-baseline sample (default 960x540 "
                     "for the reference mode, 160x90 at <= 4 spp for the extended mode)")
+    ap.add_argument("--share-of", type=int, default=0, metavar="N",
+                    help="development aid (profiles of the 8-GPU configurations on one GPU): render only rank 0's share of an N-way "
+                         "tile partition in this single process; the line is labelled as such and is not a scaling result")
     ap.add_argument("--selftest-cpu", action="store_true",
                     help="exercise only the multi-process glue (tile partition, barrier, max-reduce, frame assembly + CRC) on "
                          "CPU/gloo with a synthetic frame; renders nothing")
@@ -292,9 +295,11 @@ def main():
     ctx = api.Context((local_rank,))
     ctx.upload_scene(scene)  # scene resident in HBM before the timed region
 
+    part_world = args.share_of if (args.share_of > 1 and n_gpus == 1) else n_gpus
+
     def step(counters=False):
         return ctx.render(args.width, args.height, scene.camera, mode=mode, spp=spp, max_bounces=bounces,
-                          tile_size=tile, tile_rank=rank, tile_world=n_gpus, counters=counters,
+                          tile_size=tile, tile_rank=rank, tile_world=part_world, counters=counters,
                           kernel_sm=args.kernel == "state_machine", kernel_v1=args.kernel == "nested")
 
     for _ in range(args.warmup):
@@ -315,6 +320,8 @@ def main():
     barrier_sync(dist, torch.cuda)
     g0 = time.perf_counter()
     crc, _img = assemble_frame(dist, rank, n_gpus, ctx.read_rgb32f(), args.width, args.height, tile)
+    if part_world != n_gpus:
+        crc = None  # a share of the frame, not the frame
     gather_ms = max_over_ranks(dist, (time.perf_counter() - g0) * 1e3, dev)
 
     # exact node / triangle fetch counts and wave-level step statistics from the counting variant of the same kernels
@@ -331,8 +338,9 @@ def main():
     # bytes that have to cross the HBM interface whatever the caches do: the path state, the pixels, the scene once
     compulsory_bytes = state_bytes + stc["pixels"] * S_OUT_BYTES + stc["scene_bytes"]
 
-    workload_key = f"{scene.name}_{args.width}x{args.height}_{mode_name}"
-    prof = load_profile(workload_key) if (args.spp, args.bounces) == (64, 4) or mode_name != "extended" else None
+    workload_key = f"{scene.name}_{args.width}x{args.height}_{mode_name}" + (f"_{spp}spp_{bounces}b" if mode_name == "extended" else "") + \
+                   (f"_share{part_world}" if part_world != n_gpus else "")
+    prof = load_profile(workload_key)
     traffic = prof["traffic"] if prof else None
     if traffic is not None and n_gpus > 1 and all_rays > 0:  # measured for the whole frame on one GPU: rank 0's share by segments
         traffic = traffic * stc["rays"] / (all_rays / args.steps)
@@ -383,7 +391,8 @@ def main():
             "config": {"workload": workload, "scene": scene.name, "triangles": scene.n_triangles,
                        "resolution": [args.width, args.height], "spp": spp, "mode": mode_name,
                        "implementation": args.kernel if mode_name == "extended" else "k_render_reference",
-                       "partition": f"tiles {tile}x{tile} interleaved over {n_gpus} rank(s), scene replicated, no collective",
+                       "partition": f"tiles {tile}x{tile} interleaved over {n_gpus} rank(s), scene replicated, no collective" if part_world == n_gpus else
+                                    f"REHEARSAL: rank 0's share of a {part_world}-way partition in {tile}x{tile} tiles on one GPU (not a scaling result)",
                        "bounces": bounces if mode_name == "extended" else 0,
                        "ray_definition": "value counts camera + continuation segments (BASELINE.md 3); shadow segments are traced too and reported in all_segments_mrays_per_s",
                        "all_segments_mrays_per_s": all_rays / dt / 1e6,
