@@ -343,6 +343,236 @@ void put_tri(const BuildTri& t, DevTri* o) {
     o->leaf_count = 0;
 }
 
+// ---- 8-wide collapse (DevNode8).  Works on its own copy of the binary tree and of the id array (the collapse merges
+// small subtrees into leaves in place).  Same dynamic program as the 4-wide collapse below, with eight slots.
+constexpr int W8 = 8;
+struct Dp8 {
+    float c[W8];
+    uint8_t split[W8]; // [k-1]: slots for the left child when k are distributed (0: use k - 1); [0]: the split of 8 when the node is a wide node
+    uint8_t leaf;
+};
+
+void quantise_axis(const Box& parent, int a, float org, uint32_t& ex_out, double& scale_out) {
+    double extent = (double)parent.mx[a] - (double)parent.mn[a];
+    int e = 1;
+    if (extent > 0.0) {
+        int fe;
+        std::frexp(extent / 255.0, &fe);
+        e = fe + 127;
+        if (e < 1) e = 1;
+        if (e > 254) e = 254;
+    }
+    (void)org;
+    ex_out = (uint32_t)(e - 127) & 0xFFu;
+    scale_out = std::ldexp(1.0, e - 127);
+}
+
+void quantise_box(const Box& cb, int a, float org, double scale, uint32_t& qlo, uint32_t& qhi) {
+    double lo = std::floor(((double)cb.mn[a] - (double)org) / scale);
+    double hi = std::ceil(((double)cb.mx[a] - (double)org) / scale);
+    lo = std::min(std::max(lo, 0.0), 255.0);
+    hi = std::min(std::max(hi, 0.0), 255.0);
+    while (lo > 0.0 && (double)org + lo * scale > (double)cb.mn[a]) lo -= 1.0;
+    while (hi < 255.0 && (double)org + hi * scale < (double)cb.mx[a]) hi += 1.0;
+    qlo = (uint32_t)lo;
+    qhi = (uint32_t)hi;
+}
+
+void collapse8(std::vector<TmpNode> nodes, std::vector<uint32_t> ids, uint32_t n_nodes, uint32_t root, const BuildTri* tris_in, const BvhBuildOptions& opt,
+               uint32_t max_leaf, BvhBuild& out) {
+    auto is_leaf = [&](uint32_t t) { return nodes[t].left == 0xFFFFFFFFu; };
+    if (is_leaf(root)) return; // tiny scenes keep the leaf root of the 4-wide path
+    std::vector<Dp8> dp(n_nodes);
+    std::vector<uint32_t> sub_start(n_nodes, 0), sub_count(n_nodes, 0);
+    const float inf = std::numeric_limits<float>::infinity();
+    {
+        struct Frame {
+            uint32_t node;
+            int phase;
+        };
+        std::vector<Frame> st;
+        st.push_back({root, 0});
+        while (!st.empty()) {
+            Frame f = st.back();
+            st.pop_back();
+            const TmpNode& t = nodes[f.node];
+            Dp8& d = dp[f.node];
+            if (t.left == 0xFFFFFFFFu) {
+                const float lc = opt.cost_intersect * (float)t.count * t.box.half_area();
+                for (int k = 0; k < W8; k++) d.c[k] = lc, d.split[k] = 0;
+                d.leaf = 1;
+                sub_start[f.node] = t.start;
+                sub_count[f.node] = t.count;
+                continue;
+            }
+            if (f.phase == 0) {
+                st.push_back({f.node, 1});
+                st.push_back({t.left, 0});
+                st.push_back({t.right, 0});
+                continue;
+            }
+            const uint32_t ls = sub_start[t.left], lc_ = sub_count[t.left], rs = sub_start[t.right], rc_ = sub_count[t.right];
+            const bool contiguous = lc_ && rc_ && (ls + lc_ == rs || rs + rc_ == ls);
+            sub_start[f.node] = contiguous ? std::min(ls, rs) : 0;
+            sub_count[f.node] = contiguous ? lc_ + rc_ : 0;
+            const Dp8 &dl = dp[t.left], &dr = dp[t.right];
+            float dist[W8 + 1];
+            uint8_t arg[W8 + 1];
+            for (int k = 0; k <= W8; k++) dist[k] = inf, arg[k] = 0;
+            for (int k = 2; k <= W8; k++)
+                for (int i = 1; i < k; i++) {
+                    const float v = dl.c[i - 1] + dr.c[k - i - 1];
+                    if (v < dist[k]) dist[k] = v, arg[k] = (uint8_t)i;
+                }
+            const float area = t.box.half_area();
+            const float wide = opt.cost_traverse8 * area + dist[W8];
+            const uint32_t cnt = sub_count[f.node];
+            const float leafc = cnt && cnt <= max_leaf ? opt.cost_intersect * (float)cnt * area : inf;
+            d.leaf = leafc <= wide ? 1 : 0;
+            d.c[0] = std::min(leafc, wide);
+            d.split[0] = arg[W8];
+            for (int k = 2; k <= W8; k++) {
+                if (dist[k] < d.c[k - 2]) d.c[k - 1] = dist[k], d.split[k - 1] = arg[k];
+                else d.c[k - 1] = d.c[k - 2], d.split[k - 1] = 0;
+            }
+        }
+    }
+    std::function<void(uint32_t, int, uint32_t*, int&)> expand = [&](uint32_t m, int k, uint32_t* ch, int& nch) {
+        TmpNode& t = nodes[m];
+        if (t.left != 0xFFFFFFFFu) {
+            while (k > 1 && dp[m].split[k - 1] == 0) k--;
+            if (k > 1) {
+                const int i = dp[m].split[k - 1];
+                expand(t.left, i, ch, nch);
+                expand(t.right, k - i, ch, nch);
+                return;
+            }
+            if (dp[m].leaf) {
+                t.start = sub_start[m];
+                t.count = sub_count[m];
+                std::sort(ids.begin() + t.start, ids.begin() + t.start + t.count,
+                          [&](uint32_t x, uint32_t y) { return tris_in[x].prim_id < tris_in[y].prim_id; });
+                t.left = t.right = 0xFFFFFFFFu;
+            }
+        }
+        ch[nch++] = m;
+    };
+    struct Item {
+        uint32_t tmp, dev, depth;
+    };
+    std::vector<Item> stack;
+    out.nodes8.reserve(nodes.size() / 4 + 1);
+    out.nodes8.emplace_back();
+    stack.push_back({root, 0, 1});
+    const float root_area = nodes[root].box.half_area();
+    double cost = 0.0;
+    DevTri blank;
+    std::memset(&blank, 0, sizeof blank);
+    while (!stack.empty()) {
+        Item it = stack.back();
+        stack.pop_back();
+        out.depth8 = std::max(out.depth8, it.depth);
+        const TmpNode t = nodes[it.tmp];
+        uint32_t ch[W8];
+        int nch = 0;
+        {
+            const int i = dp[it.tmp].split[0];
+            expand(t.left, i, ch, nch);
+            expand(t.right, W8 - i, ch, nch);
+        }
+        // Slot assignment: slot s lies toward the corner (s & 1 ? +x : -x, s & 2 ? +y : -y, s & 4 ? +z : -z) of the node.
+        // Greedy: repeatedly give the (child, slot) pair with the largest projection of the child's centre offset on
+        // the slot's diagonal.
+        float pc[3];
+        for (int a = 0; a < 3; a++) pc[a] = 0.5f * t.box.mn[a] + 0.5f * t.box.mx[a];
+        float score[W8][W8];
+        for (int c = 0; c < nch; c++) {
+            const Box& cb = nodes[ch[c]].box;
+            float off[3];
+            for (int a = 0; a < 3; a++) off[a] = (0.5f * cb.mn[a] + 0.5f * cb.mx[a]) - pc[a];
+            for (int sl = 0; sl < W8; sl++) score[c][sl] = (sl & 1 ? off[0] : -off[0]) + (sl & 2 ? off[1] : -off[1]) + (sl & 4 ? off[2] : -off[2]);
+        }
+        int slot_child[W8];
+        bool child_done[W8] = {false, false, false, false, false, false, false, false};
+        for (int sl = 0; sl < W8; sl++) slot_child[sl] = -1;
+        for (int round = 0; round < nch; round++) {
+            int bc = -1, bs = -1;
+            float best = -inf;
+            for (int c = 0; c < nch; c++) {
+                if (child_done[c]) continue;
+                for (int sl = 0; sl < W8; sl++)
+                    if (slot_child[sl] < 0 && score[c][sl] > best) best = score[c][sl], bc = c, bs = sl;
+            }
+            if (bc < 0) { // only NaN scores are left (degenerate boxes): any free slot
+                for (int c = 0; c < nch && bc < 0; c++)
+                    if (!child_done[c]) bc = c;
+                for (int sl = 0; sl < W8 && bs < 0; sl++)
+                    if (slot_child[sl] < 0) bs = sl;
+            }
+            slot_child[bs] = bc;
+            child_done[bc] = true;
+        }
+        uint32_t imask = 0, lmask = 0;
+        for (int sl = 0; sl < W8; sl++) {
+            if (slot_child[sl] < 0) continue;
+            if (is_leaf(ch[slot_child[sl]])) lmask |= 1u << sl;
+            else imask |= 1u << sl;
+        }
+        const uint32_t child_base = (uint32_t)out.nodes8.size();
+        const int n_inner = __builtin_popcount(imask);
+        for (int c = 0; c < n_inner; c++) out.nodes8.emplace_back();
+        const uint32_t tri_base = (uint32_t)out.tris8.size();
+        int inner_rank = 0;
+        std::vector<Item> pushes;
+        for (int sl = 0; sl < W8; sl++) {
+            if (slot_child[sl] < 0) continue;
+            const uint32_t cn = ch[slot_child[sl]];
+            if (imask & (1u << sl)) {
+                pushes.push_back({cn, child_base + (uint32_t)inner_rank, it.depth + 1});
+                inner_rank++;
+            } else {
+                const TmpNode& lf = nodes[cn];
+                const size_t first = out.tris8.size();
+                for (uint32_t i = 0; i < RT_DEV_LEAF_STRIDE; i++) {
+                    out.tris8.push_back(blank);
+                    if (i < lf.count) put_tri(tris_in[ids[lf.start + i]], &out.tris8[first + i]);
+                }
+                out.tris8[first].leaf_count = lf.count;
+                if (root_area > 0) cost += opt.cost_intersect * lf.count * lf.box.half_area() / root_area;
+            }
+        }
+        for (int c = (int)pushes.size() - 1; c >= 0; c--) stack.push_back(pushes[c]);
+        if (root_area > 0) cost += opt.cost_traverse8 * t.box.half_area() / root_area;
+        DevNode8& d = out.nodes8[it.dev];
+        uint32_t ex[3];
+        for (int a = 0; a < 3; a++) {
+            d.org[a] = t.box.mn[a];
+            double scale;
+            quantise_axis(t.box, a, d.org[a], ex[a], scale);
+            for (int h = 0; h < 2; h++) {
+                uint32_t lo_word = 0, hi_word = 0;
+                for (int i = 0; i < 4; i++) {
+                    const int sl = 4 * h + i;
+                    uint32_t qlo = 255, qhi = 0; // empty slot: inverted, never entered
+                    if (slot_child[sl] >= 0) quantise_box(nodes[ch[slot_child[sl]]].box, a, d.org[a], scale, qlo, qhi);
+                    lo_word |= qlo << (8 * i);
+                    hi_word |= qhi << (8 * i);
+                }
+                d.qlo[a][h] = lo_word;
+                d.qhi[a][h] = hi_word;
+            }
+        }
+        d.ex_imask = ex[0] | (ex[1] << 8) | (ex[2] << 16) | (imask << 24);
+        d.child_base = child_base;
+        d.tri_base = tri_base;
+        d.lmask = lmask;
+        d._pad = 0;
+    }
+    // An empty slot can only be entered when the float evaluation cannot tell 255 grid steps apart (degenerate node, ray
+    // origin ~1e8 grid steps away).  The traversal masks the hit bits with imask | lmask, so it is never followed.
+    out.sah_cost8 = cost;
+}
+
 } // namespace
 
 void build_bvh(const BuildTri* tris_in, size_t n_in, const BvhBuildOptions& opt_in, BvhBuild& out) {
@@ -388,6 +618,21 @@ void build_bvh(const BuildTri* tris_in, size_t n_in, const BvhBuildOptions& opt_
         }
     }
 #endif
+
+    // the 8-wide variant is emitted from a copy of the binary tree on its own thread while this one emits the 4-wide tree
+    // (both collapses merge small subtrees into leaves in place); it writes nodes8 / tris8 / depth8 / sah_cost8 only
+    std::future<void> wide8_done;
+    if (opt_in.wide8)
+        wide8_done = std::async(std::launch::async, [&, nodes_copy = std::vector<TmpNode>(b.nodes.begin(), b.nodes.begin() + b.next_node.load()), ids_copy = b.ids,
+                                                     n_nodes = b.next_node.load(), root, max_leaf = b.opt.max_leaf]() mutable {
+            collapse8(std::move(nodes_copy), std::move(ids_copy), n_nodes, root, tris_in, b.opt, max_leaf, out);
+        });
+    struct Join {
+        std::future<void>& f;
+        ~Join() {
+            if (f.valid()) f.get();
+        }
+    } join_wide8{wide8_done};
 
     // ---- collapse to a 4-wide tree and emit it in the quantised layout ----
     out.tris.resize(n);

@@ -31,6 +31,11 @@ struct BvhBuild {
     uint32_t depth = 0;                   // inner-node levels of the 4-wide tree on the longest root-to-leaf path
     uint32_t n_leaves = 0;
     double sah_cost = 0.0;
+    // 8-wide variant of the same binary tree (BvhBuildOptions::wide8); an inner root always exists when nodes8 is not empty
+    std::vector<DevNode8> nodes8;
+    std::vector<DevTri> tris8; // RT_DEV_LEAF_STRIDE records per leaf
+    uint32_t depth8 = 0;
+    double sah_cost8 = 0.0;
 };
 
 struct BvhBuildOptions {
@@ -39,6 +44,8 @@ struct BvhBuildOptions {
     uint32_t max_depth = RT_DEV_MAX_BVH_DEPTH;
     float cost_traverse = 0.7f; // relative to cost_intersect: measured optimum on the headline frame (0.5-0.75: +1 % over 1.0)
     float cost_intersect = 1.0f;
+    bool wide8 = false;          // also emit the 8-wide variant
+    float cost_traverse8 = 1.0f; // its traversal cost per node (a visit tests eight boxes)
 };
 
 // Triangles with a non-finite coordinate are dropped: Möller–Trumbore can never accept

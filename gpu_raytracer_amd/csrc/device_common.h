@@ -182,7 +182,7 @@ __device__ __forceinline__ bool test_leaf(const DevTri* __restrict__ tris, uint3
 #define RT_EXPERIMENT_NO_WIDENING 0 /* measurement only */
 #endif
 #ifndef RT_FILTER_RCP
-#define RT_FILTER_RCP 0
+#define RT_FILTER_RCP 1 /* round 2: -1 % on the headline frame with both trees; the filter's error bound is derived below */
 #endif
 struct FilterRay { // per-segment constants of the box filter
     V3 o, inv;     // inv = 1/d with |d| clamped away from zero (a filter may do that; the triangle test uses the real d)
@@ -336,6 +336,60 @@ __device__ __forceinline__ bool visit_node4(const uint4* __restrict__ nodes, con
     }
     sp += extra;
     return true;
+}
+
+// One visit of the 8-wide node `idx` (DevNode8, device_layout.h): the same conservative quantised-box filter as
+// visit_node4 for eight slots, but no sort: the result is the 8-bit mask of the slots the ray enters (bit s = slot s);
+// the caller visits them in increasing (slot XOR ray octant).  Returns the mask, already restricted to occupied slots.
+template <bool COUNT>
+__device__ __forceinline__ uint32_t visit_node8(const uint4* __restrict__ nodes, uint32_t idx, const FilterRay& fr, float closest_t, Counts& cnt,
+                                                uint32_t& child_base, uint32_t& tri_base, uint32_t& imask, uint32_t& lmask) {
+    const uint4* n = nodes + (size_t)idx * 5;
+    const uint4 w0 = n[0], w1 = n[1], w2 = n[2], w3 = n[3], w4 = n[4];
+    // keep the node's loads together: the words that are only used after the box tests would otherwise be fetched there
+    uint32_t w1x = w1.x, w1y = w1.y, w1z = w1.z;
+    asm volatile("" : "+v"(w1x), "+v"(w1y), "+v"(w1z));
+    if (COUNT) cnt.nodes++;
+    const float ax = ldexpf(fr.inv.x, (int)(int8_t)(w0.w & 0xFFu)), ay = ldexpf(fr.inv.y, (int)(int8_t)((w0.w >> 8) & 0xFFu)),
+                az = ldexpf(fr.inv.z, (int)(int8_t)((w0.w >> 16) & 0xFFu));
+    const float dox = __uint_as_float(w0.x) - fr.o.x, doy = __uint_as_float(w0.y) - fr.o.y, doz = __uint_as_float(w0.z) - fr.o.z;
+    const float bx = dox * fr.inv.x, by = doy * fr.inv.y, bz = doz * fr.inv.z;
+    const float ex = fmaf(255.0f, fabsf(ax), fabsf(bx)) * RT_FILTER_SLACK;
+    const float ey = fmaf(255.0f, fabsf(ay), fabsf(by)) * RT_FILTER_SLACK;
+    const float ez = fmaf(255.0f, fabsf(az), fabsf(bz)) * RT_FILTER_SLACK;
+    const f32x2 pm = {-1.0f, 1.0f};
+    const f32x2 bx2 = __builtin_elementwise_fma((f32x2){ex, ex}, pm, (f32x2){bx, bx});
+    const f32x2 by2 = __builtin_elementwise_fma((f32x2){ey, ey}, pm, (f32x2){by, by});
+    const f32x2 bz2 = __builtin_elementwise_fma((f32x2){ez, ez}, pm, (f32x2){bz, bz});
+    const f32x2 ax2 = {ax, ax}, ay2 = {ay, ay}, az2 = {az, az};
+    const bool px = fr.inv.x >= 0.0f, py = fr.inv.y >= 0.0f, pz = fr.inv.z >= 0.0f;
+    // [half]: w2 = qlo_x[0], qlo_x[1], qlo_y[0], qlo_y[1]; w3 = qlo_z[0], qlo_z[1], qhi_x[0], qhi_x[1]; w4 = qhi_y[0], qhi_y[1], qhi_z[0], qhi_z[1]
+    const uint32_t nxw[2] = {px ? w2.x : w3.z, px ? w2.y : w3.w}, fxw[2] = {px ? w3.z : w2.x, px ? w3.w : w2.y};
+    const uint32_t nyw[2] = {py ? w2.z : w4.x, py ? w2.w : w4.y}, fyw[2] = {py ? w4.x : w2.z, py ? w4.y : w2.w};
+    const uint32_t nzw[2] = {pz ? w3.x : w4.z, pz ? w3.y : w4.w}, fzw[2] = {pz ? w4.z : w3.x, pz ? w4.w : w3.y};
+    const float limit = closest_t * 1.0000153f;
+    uint32_t miss = 0; // bit s: the ray does NOT enter slot s (sign bits of tmax - tmin, shifted in one per slot)
+#pragma unroll
+    for (int h = 1; h >= 0; h--) {
+#pragma unroll
+        for (int i = 3; i >= 0; i--) {
+            const f32x2 qx = {(float)((nxw[h] >> (8 * i)) & 0xFFu), (float)((fxw[h] >> (8 * i)) & 0xFFu)};
+            const f32x2 qy = {(float)((nyw[h] >> (8 * i)) & 0xFFu), (float)((fyw[h] >> (8 * i)) & 0xFFu)};
+            const f32x2 qz = {(float)((nzw[h] >> (8 * i)) & 0xFFu), (float)((fzw[h] >> (8 * i)) & 0xFFu)};
+            const f32x2 tx = __builtin_elementwise_fma(qx, ax2, bx2);
+            const f32x2 ty = __builtin_elementwise_fma(qy, ay2, by2);
+            const f32x2 tz = __builtin_elementwise_fma(qz, az2, bz2);
+            const float tmin = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, 0.0f));
+            const float tmax = fminf(fminf(tx.y, ty.y), fminf(tz.y, limit));
+            // entered <=> tmin <= tmax <=> tmax - tmin >= +0 (all finite): v_alignbit shifts the sign bit in; slot 4h+i ends up in bit 4h+i
+            miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(tmax - tmin), 31);
+        }
+    }
+    child_base = w1x;
+    tri_base = w1y;
+    lmask = w1z & 0xFFu;
+    imask = w0.w >> 24;
+    return ~miss & (imask | lmask);
 }
 
 // ANY_HIT (shadow segments of the extended mode): return at the first accepted triangle.

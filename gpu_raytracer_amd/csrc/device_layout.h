@@ -55,6 +55,26 @@ struct DevNode4 { // 48 bytes, 16-byte aligned
 #define RT_DEV_MAX_NODES 0x00FFFFFFu
 #define RT_DEV_TRI_BASE_MASK 0x07FFFFFFu
 
+// 8-wide variant (experiment of round 2, after Ylitie, Karras, Laine, "Efficient Incoherent Ray Traversal on GPUs Through
+// Compressed Wide BVHs", 2017): 80 bytes = 5 x dwordx4, up to eight children in SLOTS chosen by the builder so that a
+// child's slot number says toward which corner of the node it lies (bit a set: the high side of axis a).  A ray visits
+// the children it enters in increasing (slot XOR ray octant): no distance sort.  Inner children are consecutive nodes in
+// slot order (child = child_base + number of inner slots below it), every leaf child owns RT_DEV_LEAF_STRIDE consecutive
+// triangle records in slot order (first = tri_base + stride * number of leaf slots below it; the run length is in the
+// first record as before), so what is left of a node after a visit is a (base, 8-bit mask) pair: one stack entry
+// per visit instead of up to three.
+struct DevNode8 { // 80 bytes, 16-byte aligned
+    float org[3];         // quantisation origin (the node's box minimum)
+    uint32_t ex_imask;    // byte 0..2: signed exponent of axis x,y,z; byte 3: slots holding an inner child
+    uint32_t child_base;  // node index of the first inner child
+    uint32_t tri_base;    // triangle record of the first leaf child
+    uint32_t lmask;       // byte 0: slots holding a leaf
+    uint32_t _pad;
+    uint32_t qlo[3][2];   // [axis][half]: byte i = quantised lower plane of slot 4 * half + i
+    uint32_t qhi[3][2];   // upper planes; empty slots are inverted (lo 255, hi 0)
+};
+#define RT_DEV_LEAF_STRIDE 4u
+
 struct DevTri { // 48 bytes, 16-byte aligned
     float v0[3];
     float e1[3];
@@ -103,6 +123,11 @@ struct DevScene {
     uint32_t n_materials; // `materials.len()` of shader/src/lib.rs:307 := material_count
     uint32_t root_ref;    // child reference of the root (a leaf reference for tiny scenes)
     uint32_t stack_entries; // per-lane LDS stack entries the kernels must provide: 3 * depth + 1
+    // 8-wide experiment: its own node and triangle arrays (leaf order and padding differ)
+    const DevNode8* nodes8;
+    const DevTri* tris8;
+    uint32_t n_nodes8;
+    uint32_t stack_entries8; // 64-bit entries: at most 2 per level + 2
 };
 
 // Camera terms that do not depend on the pixel, computed once on the host in the

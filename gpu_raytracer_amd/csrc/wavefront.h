@@ -53,6 +53,7 @@ struct WfBuffers {
     uint32_t n_blocks;   // 8x8 pixel blocks owned by this device
     uint32_t batch;      // samples per pixel in flight
     uint32_t capacity;   // path slots
+    uint32_t use8;       // experiment: the traversal stages walk the 8-wide tree (DevScene::nodes8 / tris8)
 };
 
 #define WF_TOTAL_ERROR 15 /* totals[] slot: non-zero = a queue reservation did not fit; every later stage kernel of the frame returns at once */

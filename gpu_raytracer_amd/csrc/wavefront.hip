@@ -354,6 +354,231 @@ __global__ __launch_bounds__(WAVE, RT_WF_MIN_WAVES) void k_wf_trace(DevScene sc,
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// 8-wide variant of the persistent traversal kernel (experiment, DevNode8).  What is left of a visited node is a group:
+// (base, hit mask | kind mask << 8) - G for its inner children, T for its leaves - so a visit pushes at most two 64-bit
+// entries, and children are taken from a group in increasing (slot XOR ray octant) through a 2 KB table in LDS.
+// ---------------------------------------------------------------------------------------------------------
+#ifndef RT_WF8_LDS_STACK
+#define RT_WF8_LDS_STACK 8 /* 64-bit entries per lane kept in LDS; deeper ones go to the HBM overflow area */
+#endif
+#ifndef RT_WF8_MIN_WAVES
+#define RT_WF8_MIN_WAVES 5
+#endif
+#ifndef RT_WF8_LEAF_THRESHOLD
+#define RT_WF8_LEAF_THRESHOLD 24
+#endif
+#define WF8_KIND_T 0x80000000u
+#define WF8_NONE 0xFFFFFFFFu
+
+template <bool COUNT, bool ANY>
+__global__ __launch_bounds__(WAVE, RT_WF8_MIN_WAVES) void k_wf_trace8(DevScene sc, rt::WfBuffers wb, const uint32_t* __restrict__ queue, uint32_t count_slot,
+                                                    uint32_t cursor_slot, uint32_t window_slot) {
+    extern __shared__ uint32_t s_mem8[];
+    if (wb.totals[WF_TOTAL_ERROR] != 0ull) return;
+    const uint32_t lane = threadIdx.x;
+    uint2* __restrict__ stack = reinterpret_cast<uint2*>(s_mem8) + lane;                  // entry k of this lane: stack[k * 64]
+    uint8_t* __restrict__ lut = reinterpret_cast<uint8_t*>(s_mem8 + RT_WF8_LDS_STACK * 2 * WAVE); // [octant][mask] -> slot to take next
+    for (uint32_t e = lane; e < 2048u; e += WAVE) {
+        const uint32_t oct = e >> 8, m = e & 255u;
+        uint32_t best = 0u, best_key = 99u;
+        for (uint32_t i = 0; i < 8u; i++)
+            if (((m >> i) & 1u) && (i ^ oct) < best_key) best_key = i ^ oct, best = i;
+        lut[e] = (uint8_t)best;
+    }
+    __syncthreads();
+    uint2* __restrict__ ovf = reinterpret_cast<uint2*>(wb.stack_ovf) + (size_t)blockIdx.x * wb.ovf_entries * WAVE + lane;
+    const uint4* __restrict__ nodes = reinterpret_cast<const uint4*>(sc.nodes8);
+    const uint32_t count = wb.counters[count_slot];
+    const uint32_t window_mask = max(wb.counters[window_slot], 1u) - 1u;
+    uint32_t* cursor = &wb.counters[cursor_slot];
+    Counts cnt = {0u, 0u};
+    int sp_max = 0;
+    uint32_t d_node_steps = 0, d_leaf_steps = 0, d_leaf_lanes = 0, d_leaf_trips = 0, d_refills = 0;
+
+    bool active = false, exhausted = false;
+    uint32_t chunk_next = 0, chunk_end = 0;
+    uint32_t id = 0, li = 0;
+    V3 o = v3(0.0f, 0.0f, 0.0f), d = o;
+    FilterRay fray;
+    fray.o = o;
+    fray.inv = o;
+    Hit hit;
+    hit.t = RT_F32_MAX;
+    hit.prim = RT_PRIM_MISS;
+    hit.slot = 0;
+    uint32_t cur = WF8_NONE;          // node to visit next
+    uint32_t g_base = 0, g_bits = 0;  // inner children still to visit: child_base, hit mask | imask << 8
+    uint32_t t_base = 0, t_bits = 0;  // the postponed leaf group: tri_base, hit mask | lmask << 8
+    uint32_t oct = 0;                 // table row of this segment: (dx < 0) | (dy < 0) << 1 | (dz < 0) << 2, times 256
+    int sp = 0;
+
+    for (;;) {
+        const unsigned long long idle = __ballot(!active);
+        if (!exhausted && (__popcll(idle) >= RT_WF_REFILL || idle == ~0ull)) {
+            if (chunk_next >= chunk_end) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(cursor, (uint32_t)RT_WF_CHUNK);
+                base = __shfl(base, 0, WAVE);
+                chunk_next = base;
+                chunk_end = min(base + (uint32_t)RT_WF_CHUNK, count);
+                if (base >= count) exhausted = true;
+            }
+            if (!exhausted) {
+                if (COUNT) d_refills++;
+                const uint32_t n_fetch = (uint32_t)__popcll(idle);
+                const uint32_t idx = chunk_next + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                const uint32_t last = min(chunk_next + n_fetch, chunk_end) - 1u;
+                chunk_next += n_fetch;
+                uint32_t e = WF_SENTINEL;
+                if (!active && idx < chunk_end) e = queue[idx];
+                if (__ballot(!active && idx == last && e == WF_SENTINEL) != 0ull) chunk_next = max(chunk_next, (last + window_mask + 1u) & ~window_mask);
+                if (e != WF_SENTINEL) {
+                    if (ANY) {
+                        id = e & RT_WF_ID_MASK;
+                        li = e >> 27;
+                        const V3 point = f4v(wb.vtx_p[id]), normal = f4v(wb.vtx_n[id]);
+                        float dist;
+                        shadow_segment(sc.lights[li], point, d, dist);
+                        o = point + normal * EXT_EPS;
+                        hit.t = dist;
+                    } else {
+                        id = e;
+                        o = f4v(wb.ray_o[id]);
+                        d = f4v(wb.ray_d[id]);
+                        hit.t = RT_F32_MAX;
+                    }
+                    hit.prim = RT_PRIM_MISS;
+                    hit.slot = 0;
+                    fray = make_filter_ray(o, d);
+                    oct = ((fray.inv.x < 0.0f ? 1u : 0u) | (fray.inv.y < 0.0f ? 2u : 0u) | (fray.inv.z < 0.0f ? 4u : 0u)) << 8;
+                    test_spheres(sc, o, d, hit);
+                    sp = 0;
+                    cur = WF8_NONE;
+                    t_bits = 0;
+                    // the root as the only child of a group: node 0 (an inner root always exists when the scene has more than one leaf)
+                    g_base = 0;
+                    g_bits = sc.n_nodes8 ? (1u | (1u << 8)) : 0u;
+                    if (sc.n_nodes8 == 0 && sc.n_tris) { // the whole scene is one leaf at record 0
+                        t_base = 0;
+                        t_bits = 1u | (1u << 8);
+                    }
+                    active = true;
+                    if (ANY && hit.prim != RT_PRIM_MISS) g_bits = t_bits = 0; // occluded by a sphere already
+                }
+            }
+        }
+        if (__ballot(active) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+        for (;;) {
+            // ---- fetch: lanes without a node take the next child of their group, or the next group off the stack
+            if (active && cur == WF8_NONE) {
+                if ((g_bits & 0xFFu) == 0u && sp > 0) {
+                    const int k = sp - 1;
+                    uint2 e;
+                    if (__ballot(k >= RT_WF8_LDS_STACK) == 0ull) e = stack[k * WAVE]; // wave-uniform: the common case stays a plain ds_read_b64
+                    else if (k < RT_WF8_LDS_STACK) e = stack[k * WAVE];
+                    else e = ovf[(k - RT_WF8_LDS_STACK) * WAVE];
+                    if (!(e.x & WF8_KIND_T)) {
+                        sp = k;
+                        g_base = e.x;
+                        g_bits = e.y;
+                    } else if ((t_bits & 0xFFu) == 0u) {
+                        sp = k;
+                        t_base = e.x & ~WF8_KIND_T;
+                        t_bits = e.y;
+                    }
+                }
+                if (g_bits & 0xFFu) {
+                    const uint32_t i = lut[oct + (g_bits & 0xFFu)];
+                    g_bits ^= 1u << i;                                                   // the bit is set
+                    cur = g_base + (uint32_t)__popc(__builtin_amdgcn_ubfe(g_bits, 8u, i)); // inner slots below i
+                }
+            }
+            const bool can_node = active && cur != WF8_NONE;
+            const bool has_leaf = active && (t_bits & 0xFFu) != 0u;
+            const unsigned long long m_node = __ballot(can_node), m_leaf = __ballot(has_leaf);
+            if (m_node != 0ull && __popcll(m_leaf) < RT_WF8_LEAF_THRESHOLD) {
+                if (COUNT) d_node_steps++;
+                if (can_node) {
+                    uint32_t cb, tb, im, lm;
+                    const uint32_t hm = visit_node8<COUNT>(nodes, cur, fray, hit.t, cnt, cb, tb, im, lm);
+                    cur = WF8_NONE;
+                    if (g_bits & 0xFFu) { // siblings still to visit: park them
+                        if (sp < RT_WF8_LDS_STACK) stack[sp * WAVE] = make_uint2(g_base, g_bits);
+                        else ovf[(sp - RT_WF8_LDS_STACK) * WAVE] = make_uint2(g_base, g_bits);
+                        sp++;
+                    }
+                    g_base = cb;
+                    g_bits = (hm & im) | (im << 8);
+                    const uint32_t nt = hm & lm;
+                    if (nt) {
+                        if ((t_bits & 0xFFu) == 0u) {
+                            t_base = tb;
+                            t_bits = nt | (lm << 8);
+                        } else {
+                            if (sp < RT_WF8_LDS_STACK) stack[sp * WAVE] = make_uint2(tb | WF8_KIND_T, nt | (lm << 8));
+                            else ovf[(sp - RT_WF8_LDS_STACK) * WAVE] = make_uint2(tb | WF8_KIND_T, nt | (lm << 8));
+                            sp++;
+                        }
+                    }
+                    if (COUNT) sp_max = max(sp_max, sp);
+                }
+            } else if (m_leaf != 0ull) {
+                uint32_t trips = 0;
+                if (has_leaf) {
+                    const uint32_t before = cnt.tris;
+                    const uint32_t i = lut[oct + (t_bits & 0xFFu)];
+                    t_bits ^= 1u << i;
+                    const uint32_t first = t_base + RT_DEV_LEAF_STRIDE * (uint32_t)__popc(__builtin_amdgcn_ubfe(t_bits, 8u, i));
+                    if (test_leaf<COUNT, ANY>(sc.tris8, RT_DEV_LEAF_FLAG | first, o, d, hit, cnt)) { // occluded: nothing more to do
+                        cur = WF8_NONE;
+                        g_bits = t_bits = 0u;
+                        sp = 0;
+                    }
+                    trips = cnt.tris - before;
+                }
+                if (COUNT) {
+                    d_leaf_steps++;
+                    d_leaf_lanes += (uint32_t)__popcll(m_leaf);
+                    for (int off = 32; off > 0; off >>= 1) trips = max(trips, (uint32_t)__shfl_xor((int)trips, off, WAVE));
+                    d_leaf_trips += trips;
+                }
+            }
+            if (active && cur == WF8_NONE && (g_bits & 0xFFu) == 0u && (t_bits & 0xFFu) == 0u && sp == 0) { // segment finished
+                if (ANY) {
+                    if (hit.prim == RT_PRIM_MISS) atomicOr(reinterpret_cast<uint32_t*>(&wb.vtx_n[id]) + 3, 1u << li);
+                } else {
+                    const V3 hp = o + d * hit.t;
+                    const uint32_t code = hit.prim == RT_PRIM_MISS ? RT_PRIM_MISS : ((hit.prim & RT_PRIM_SPHERE_FLAG) ? hit.prim : hit.slot);
+                    wb.hit[id] = make_uint4(__float_as_uint(hp.x), __float_as_uint(hp.y), __float_as_uint(hp.z), code);
+                }
+                active = false;
+            }
+            const unsigned long long still = __ballot(active);
+            if (still == 0ull) break;
+            if (!exhausted && __popcll(~still) >= RT_WF_REFILL) break;
+        }
+    }
+    if (COUNT) {
+        unsigned long long n0 = wave_sum(cnt.nodes), n1 = wave_sum(cnt.tris);
+        for (int off = 32; off > 0; off >>= 1) sp_max = max(sp_max, __shfl_down(sp_max, off, WAVE));
+        if (lane == 0) {
+            atomicAdd(&wb.totals[3], n0);
+            atomicAdd(&wb.totals[4], n1);
+            atomicMax(&wb.totals[5], (unsigned long long)sp_max);
+            atomicAdd(&wb.totals[8], (unsigned long long)d_node_steps);
+            atomicAdd(&wb.totals[9], (unsigned long long)d_leaf_steps);
+            atomicAdd(&wb.totals[10], (unsigned long long)d_leaf_lanes);
+            atomicAdd(&wb.totals[11], (unsigned long long)d_leaf_trips);
+            atomicAdd(&wb.totals[12], (unsigned long long)d_refills);
+        }
+    }
+}
+
 // The shading stages are bound by memory latency, not arithmetic (22 % VALU busy, 83 % of the wave time in s_waitcnt):
 // what counts is the number of DEPENDENT round trips per path.  Lights come from LDS (staged once per block), and
 // each group of per-path loads is issued together: RT_KEEP4 pins the loaded values at one point so the
@@ -389,6 +614,7 @@ __device__ __forceinline__ void wf_end_path(const rt::WfBuffers& wb, uint32_t id
 
 __global__ __launch_bounds__(256, RT_WF_SHADE_WAVES) void k_wf_shade(DevScene sc, DevFrame fr, rt::WfBuffers wb, const uint32_t* __restrict__ queue) {
     __shared__ DevLight s_lights[RT_WF_MAX_LIGHTS];
+    if (wb.use8) sc.tris = sc.tris8; // hit records name triangle slots of the array the traversal walked
     if (wb.totals[WF_TOTAL_ERROR] != 0ull) return;
     stage_lights(s_lights, sc);
     const uint32_t count = wb.counters[rt::WF_EXT_COUNT];
@@ -705,22 +931,30 @@ hipError_t wf_generate(const DevScene&, const DevFrame& fr, const WfBuffers& wb,
     return hipGetLastError();
 }
 
+template <bool COUNT, bool ANY>
+static void launch_trace(const DevScene& sc, const WfBuffers& wb, const uint32_t* q, uint32_t count_slot, uint32_t cursor_slot, uint32_t window_slot, hipStream_t s) {
+    const dim3 pgrid(wf_persistent_waves()), pblock(WAVE);
+    if (wb.use8) {
+        const size_t lds8 = (size_t)RT_WF8_LDS_STACK * WAVE * sizeof(uint2) + 2048;
+        hipLaunchKernelGGL((k_wf_trace8<COUNT, ANY>), pgrid, pblock, lds8, s, sc, wb, q, count_slot, cursor_slot, window_slot);
+    } else {
+        const size_t lds = (size_t)RT_WF_LDS_STACK * WAVE * sizeof(uint32_t);
+        hipLaunchKernelGGL((k_wf_trace<COUNT, ANY>), pgrid, pblock, lds, s, sc, wb, q, count_slot, cursor_slot, window_slot);
+    }
+}
+
 hipError_t wf_bounce(const DevScene& sc, const DevFrame& fr, const WfBuffers& wb, uint32_t iteration, bool counters, hipStream_t s) {
     const size_t lds = (size_t)RT_WF_LDS_STACK * WAVE * sizeof(uint32_t);
-    const dim3 pgrid(wf_persistent_waves()), pblock(WAVE);
+    (void)lds;
     const dim3 sgrid(wf_shading_blocks()), sblock(256);
     uint32_t* cur_q = wb.q_ext[iteration & 1u];
     uint32_t* next_q = wb.q_ext[(iteration + 1u) & 1u];
-    if (counters)
-        hipLaunchKernelGGL((k_wf_trace<true, false>), pgrid, pblock, lds, s, sc, wb, (const uint32_t*)cur_q, (uint32_t)WF_EXT_COUNT, (uint32_t)WF_EXT_CURSOR, (uint32_t)WF_EXT_WINDOW);
-    else
-        hipLaunchKernelGGL((k_wf_trace<false, false>), pgrid, pblock, lds, s, sc, wb, (const uint32_t*)cur_q, (uint32_t)WF_EXT_COUNT, (uint32_t)WF_EXT_CURSOR, (uint32_t)WF_EXT_WINDOW);
+    if (counters) launch_trace<true, false>(sc, wb, cur_q, WF_EXT_COUNT, WF_EXT_CURSOR, WF_EXT_WINDOW, s);
+    else launch_trace<false, false>(sc, wb, cur_q, WF_EXT_COUNT, WF_EXT_CURSOR, WF_EXT_WINDOW, s);
     hipLaunchKernelGGL(k_wf_shade, sgrid, sblock, 0, s, sc, fr, wb, (const uint32_t*)cur_q);
     if ((fr.flags & 2u) == 0) {
-        if (counters)
-            hipLaunchKernelGGL((k_wf_trace<true, true>), pgrid, pblock, lds, s, sc, wb, (const uint32_t*)wb.q_shadow, (uint32_t)WF_SHADOW_COUNT, (uint32_t)WF_SHADOW_CURSOR, (uint32_t)WF_SHADOW_WINDOW);
-        else
-            hipLaunchKernelGGL((k_wf_trace<false, true>), pgrid, pblock, lds, s, sc, wb, (const uint32_t*)wb.q_shadow, (uint32_t)WF_SHADOW_COUNT, (uint32_t)WF_SHADOW_CURSOR, (uint32_t)WF_SHADOW_WINDOW);
+        if (counters) launch_trace<true, true>(sc, wb, wb.q_shadow, WF_SHADOW_COUNT, WF_SHADOW_CURSOR, WF_SHADOW_WINDOW, s);
+        else launch_trace<false, true>(sc, wb, wb.q_shadow, WF_SHADOW_COUNT, WF_SHADOW_CURSOR, WF_SHADOW_WINDOW, s);
     }
     hipLaunchKernelGGL(k_wf_finish, sgrid, sblock, 0, s, sc, fr, wb, (const uint32_t*)cur_q, next_q);
     hipLaunchKernelGGL(k_wf_advance, dim3(1), dim3(1), 0, s, wb, iteration);
