@@ -444,15 +444,14 @@ __device__ __forceinline__ V3 evaluate_brdf(const DevMaterial& m, float intensit
 // length of the segment toward the light (used by the extended mode's shadow rays).
 __device__ __forceinline__ V3 light_contribution(const DevLight& L, const DevMaterial& m, V3 point, V3 normal, V3& to_light_dir,
                                                  float& to_light_dist) {
-    V3 ldir = ld3(L.direction);
-    V3 dir_light_dir = -normalize(ldir); // lighting.rs:103
+    V3 dir_light_dir = ld3(L.neg_ndir); // -normalize(direction), lighting.rs:103 (per-light constant, DevLight)
     float dir_intensity = fmaxf(dot(normal, dir_light_dir), 0.0f) * L.intensity;
     V3 to_light = ld3(L.position) - point; // lighting.rs:120-122
     float distance = length(to_light);
     V3 pld = normalize(to_light);
     float att = f16_round_trip(1.0f / (1.0f + distance * distance * 0.01f)); // :125-127
     float point_intensity = fmaxf(dot(normal, pld), 0.0f) * L.intensity * att;
-    float spot_factor = fmaxf(dot(-normalize(ldir), pld), 0.0f); // :132
+    float spot_factor = fmaxf(dot(dir_light_dir, pld), 0.0f); // :132 (the same -normalize(direction))
     float spot_intensity = point_intensity * spot_factor;
     float is_dir = (L.light_type == 0) ? 1.0f : 0.0f;
     float is_point = (L.light_type == 1) ? 1.0f : 0.0f;
@@ -639,7 +638,7 @@ __device__ __forceinline__ unsigned long long wave_sum(uint32_t v) {
 // light_contribution evaluates (lighting.rs:103, 120-122), so both produce the same bits.
 __device__ __forceinline__ void shadow_segment(const DevLight& L, V3 point, V3& dir, float& dist) {
     if (L.light_type == 0) {
-        dir = -normalize(ld3(L.direction));
+        dir = ld3(L.neg_ndir);
         dist = RT_F32_MAX;
     } else {
         V3 to_light = ld3(L.position) - point;

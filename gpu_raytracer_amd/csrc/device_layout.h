@@ -101,13 +101,15 @@ struct DevSphere { // 32 bytes
     uint32_t _pad[3];
 };
 
-struct DevLight { // 48 bytes: the 11 words of Light the kernel reads (shader/src/scene_access.rs:60-107)
+struct DevLight { // 64 bytes: the 11 words of Light the kernel reads (shader/src/scene_access.rs:60-107) + one per-light constant
     float position[3];
     uint32_t light_type;
     float color[3];
     float intensity;
     float direction[3];
     uint32_t _pad;
+    float neg_ndir[3]; // -normalize(direction) (lighting.rs:103, 132): the same for every pixel, so evaluated once at upload, by
+    uint32_t _pad2;    // the host, in the same f32 operation order (x*x + y*y + z*z, IEEE sqrt and divide): same bits
 };
 
 struct DevScene {

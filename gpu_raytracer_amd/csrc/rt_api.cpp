@@ -253,6 +253,13 @@ int upload_common(rt_ctx* ctx, const rt_sphere* spheres, uint32_t n_spheres, con
         dl[i].intensity = lights[i].intensity;
         std::memcpy(dl[i].direction, lights[i].direction, 12);
         dl[i]._pad = 0;
+        { // -normalize(direction): glam scalar-math normalize = v * (1 / sqrt(dot(v, v))), dot = (x*x + y*y) + z*z; this file is built -ffp-contract=off
+            const float* v = lights[i].direction;
+            const volatile float len2 = (v[0] * v[0]) + (v[1] * v[1]) + (v[2] * v[2]);
+            const volatile float inv = 1.0f / std::sqrt(len2);
+            for (int a = 0; a < 3; a++) dl[i].neg_ndir[a] = -(v[a] * inv);
+            dl[i]._pad2 = 0;
+        }
     }
     std::vector<DevMaterial> dm(n_materials);
     for (uint32_t i = 0; i < n_materials; i++) { // MaterialEvaluator accessors, shader/src/material.rs:16-63

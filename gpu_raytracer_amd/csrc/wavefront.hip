@@ -364,7 +364,7 @@ __global__ __launch_bounds__(WAVE, RT_WF_MIN_WAVES) void k_wf_trace(DevScene sc,
 #define RT_WF8_LDS_STACK 8 /* 64-bit entries per lane kept in LDS; deeper ones go to the HBM overflow area */
 #endif
 #ifndef RT_WF8_MIN_WAVES
-#define RT_WF8_MIN_WAVES 5
+#define RT_WF8_MIN_WAVES 6 /* 80 VGPRs: measured, 82 VGPRs (5 waves per SIMD) cost 4 % */
 #endif
 #ifndef RT_WF8_LEAF_THRESHOLD
 #define RT_WF8_LEAF_THRESHOLD 24
