@@ -14,7 +14,8 @@ src, out = sys.argv[1], sys.argv[2]
 arg = lambda k, d=None: sys.argv[sys.argv.index(k) + 1] if k in sys.argv else d
 key, frames, match = arg("--workload"), int(arg("--frames", "1")), arg("--match", "k_render")
 os.makedirs(os.path.dirname(out), exist_ok=True)
-stats = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[0]
+newest = lambda pattern: sorted(glob.glob(pattern), key=os.path.getmtime)  # gpurun merges runs into gpurun_out/: take the latest
+stats = newest(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[-1]
 shutil.copy(stats, out + "_kernel_stats.csv")
 import re
 rows = [r for r in csv.DictReader(open(stats)) if match in r["Name"] and "<true" not in r["Name"]]
@@ -34,11 +35,11 @@ summary["kernel_ms_per_frame"] = sum(v["total_ms_per_frame"] for v in summary["k
 pmc = {}
 by_kernel = collections.defaultdict(dict)
 for d in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq", "pmc_sq2", "pmc_sq3"):
-    fs = glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv"))
+    fs = newest(os.path.join(src, d, "*", "*_counter_collection.csv"))
     if not fs:
         continue
     agg = collections.defaultdict(float)
-    for r in csv.DictReader(open(fs[0])):
+    for r in csv.DictReader(open(fs[-1])):
         if match in r["Kernel_Name"] and "<true" not in r["Kernel_Name"]:
             v = float(r["Counter_Value"]) / nframes(r["Kernel_Name"])
             agg[r["Counter_Name"]] += v
