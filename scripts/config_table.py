@@ -3,7 +3,7 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gpu_raytracer_amd import api, scenes
 rows = [("cornell12", 256, 256, 1, 0, 1, 1), ("cornell12", 1920, 1080, 64, 0, 1, 1), ("sponza_like", 1920, 1080, 16, 4, 1, 1),
-        ("sponza_like", 1920, 1080, 64, 4, 1, 1), ("sponza_like", 3840, 2160, 32, 8, 8, 32), ("bistro_like", 3840, 2160, 8, 4, 8, 32),
+        ("sponza_like", 1920, 1080, 64, 4, 1, 1), ("sponza_like", 3840, 2160, 256, 8, 8, 32), ("bistro_like", 3840, 2160, 64, 8, 8, 32),
         ("bistro_like", 1920, 1080, 16, 4, 1, 128)]
 last = None
 with api.Context() as ctx:
