@@ -1,4 +1,4 @@
-// bvh_builder.cpp — binned-SAH binary build (host, multi-threaded) collapsed into the 4-wide quantised layout, see bvh_builder.h.
+// bvh_builder.cpp — binned-SAH binary build (host, multi-threaded) collapsed into the 8-wide quantised layout, see bvh_builder.h.
 #include "bvh_builder.h"
 
 #include <algorithm>
@@ -343,8 +343,12 @@ void put_tri(const BuildTri& t, DevTri* o) {
     o->leaf_count = 0;
 }
 
-// ---- 8-wide collapse (DevNode8).  Works on its own copy of the binary tree and of the id array (the collapse merges
-// small subtrees into leaves in place).  Same dynamic program as the 4-wide collapse below, with eight slots.
+// ---- 8-wide collapse (DevNode8).  Which binary nodes become wide nodes, which are absorbed, which subtrees become one leaf is
+// chosen by dynamic programming over the binary tree (minimum expected cost): c[k-1] = cheapest cost of a subtree when it may
+// occupy at most k child slots of its wide parent: k = 1: either one leaf (<= max_leaf triangles) or a wide node of its own,
+// area * cost_traverse8 + the best split of 8 slots between its two children; k > 1: the best split of k slots between its
+// children, or k - 1 slots.  (Round 1's 4-wide collapse used the same program with four slots; the greedy "open the child with
+// the largest area" rule it replaced was 0.8-1.5 % worse.)
 constexpr int W8 = 8;
 struct Dp8 {
     float c[W8];
@@ -378,10 +382,41 @@ void quantise_box(const Box& cb, int a, float org, double scale, uint32_t& qlo, 
     qhi = (uint32_t)hi;
 }
 
-void collapse8(std::vector<TmpNode> nodes, std::vector<uint32_t> ids, uint32_t n_nodes, uint32_t root, const BuildTri* tris_in, const BvhBuildOptions& opt,
+void collapse8(std::vector<TmpNode>& nodes, std::vector<uint32_t>& ids, uint32_t n_nodes, uint32_t root, const BuildTri* tris_in, const BvhBuildOptions& opt,
                uint32_t max_leaf, BvhBuild& out) {
     auto is_leaf = [&](uint32_t t) { return nodes[t].left == 0xFFFFFFFFu; };
-    if (is_leaf(root)) return; // tiny scenes keep the leaf root of the 4-wide path
+    DevTri blank;
+    std::memset(&blank, 0, sizeof blank);
+    if (is_leaf(root)) { // the whole scene is one leaf: a root node with that one child in slot 0, so that every walk starts at node 0
+        const TmpNode& t = nodes[root];
+        out.nodes.emplace_back();
+        DevNode8& d = out.nodes[0];
+        uint32_t ex[3];
+        for (int a = 0; a < 3; a++) {
+            d.org[a] = t.box.mn[a];
+            double scale;
+            quantise_axis(t.box, a, d.org[a], ex[a], scale);
+            uint32_t qlo, qhi;
+            quantise_box(t.box, a, d.org[a], scale, qlo, qhi);
+            d.qlo[a][0] = qlo | 0xFFFFFF00u; // slots 1..7 empty: inverted
+            d.qhi[a][0] = qhi;
+            d.qlo[a][1] = 0xFFFFFFFFu;
+            d.qhi[a][1] = 0u;
+        }
+        d.ex_imask = ex[0] | (ex[1] << 8) | (ex[2] << 16);
+        d.child_base = 0;
+        d.tri_base = 0;
+        d.lmask = 1u;
+        d._pad = 0;
+        for (uint32_t i = 0; i < RT_DEV_LEAF_STRIDE; i++) {
+            out.tris.push_back(blank);
+            if (i < t.count) put_tri(tris_in[ids[t.start + i]], &out.tris[i]);
+        }
+        out.tris[0].leaf_count = t.count;
+        out.n_leaves = 1;
+        out.depth = 1;
+        return;
+    }
     std::vector<Dp8> dp(n_nodes);
     std::vector<uint32_t> sub_start(n_nodes, 0), sub_count(n_nodes, 0);
     const float inf = std::numeric_limits<float>::infinity();
@@ -461,17 +496,15 @@ void collapse8(std::vector<TmpNode> nodes, std::vector<uint32_t> ids, uint32_t n
         uint32_t tmp, dev, depth;
     };
     std::vector<Item> stack;
-    out.nodes8.reserve(nodes.size() / 4 + 1);
-    out.nodes8.emplace_back();
+    out.nodes.reserve(nodes.size() / 4 + 1);
+    out.nodes.emplace_back();
     stack.push_back({root, 0, 1});
     const float root_area = nodes[root].box.half_area();
     double cost = 0.0;
-    DevTri blank;
-    std::memset(&blank, 0, sizeof blank);
     while (!stack.empty()) {
         Item it = stack.back();
         stack.pop_back();
-        out.depth8 = std::max(out.depth8, it.depth);
+        out.depth = std::max(out.depth, it.depth);
         const TmpNode t = nodes[it.tmp];
         uint32_t ch[W8];
         int nch = 0;
@@ -518,10 +551,10 @@ void collapse8(std::vector<TmpNode> nodes, std::vector<uint32_t> ids, uint32_t n
             if (is_leaf(ch[slot_child[sl]])) lmask |= 1u << sl;
             else imask |= 1u << sl;
         }
-        const uint32_t child_base = (uint32_t)out.nodes8.size();
+        const uint32_t child_base = (uint32_t)out.nodes.size();
         const int n_inner = __builtin_popcount(imask);
-        for (int c = 0; c < n_inner; c++) out.nodes8.emplace_back();
-        const uint32_t tri_base = (uint32_t)out.tris8.size();
+        for (int c = 0; c < n_inner; c++) out.nodes.emplace_back();
+        const uint32_t tri_base = (uint32_t)out.tris.size();
         int inner_rank = 0;
         std::vector<Item> pushes;
         for (int sl = 0; sl < W8; sl++) {
@@ -532,18 +565,19 @@ void collapse8(std::vector<TmpNode> nodes, std::vector<uint32_t> ids, uint32_t n
                 inner_rank++;
             } else {
                 const TmpNode& lf = nodes[cn];
-                const size_t first = out.tris8.size();
+                const size_t first = out.tris.size();
                 for (uint32_t i = 0; i < RT_DEV_LEAF_STRIDE; i++) {
-                    out.tris8.push_back(blank);
-                    if (i < lf.count) put_tri(tris_in[ids[lf.start + i]], &out.tris8[first + i]);
+                    out.tris.push_back(blank);
+                    if (i < lf.count) put_tri(tris_in[ids[lf.start + i]], &out.tris[first + i]);
                 }
-                out.tris8[first].leaf_count = lf.count;
+                out.tris[first].leaf_count = lf.count;
+                out.n_leaves++;
                 if (root_area > 0) cost += opt.cost_intersect * lf.count * lf.box.half_area() / root_area;
             }
         }
         for (int c = (int)pushes.size() - 1; c >= 0; c--) stack.push_back(pushes[c]);
         if (root_area > 0) cost += opt.cost_traverse8 * t.box.half_area() / root_area;
-        DevNode8& d = out.nodes8[it.dev];
+        DevNode8& d = out.nodes[it.dev];
         uint32_t ex[3];
         for (int a = 0; a < 3; a++) {
             d.org[a] = t.box.mn[a];
@@ -570,7 +604,7 @@ void collapse8(std::vector<TmpNode> nodes, std::vector<uint32_t> ids, uint32_t n
     }
     // An empty slot can only be entered when the float evaluation cannot tell 255 grid steps apart (degenerate node, ray
     // origin ~1e8 grid steps away).  The traversal masks the hit bits with imask | lmask, so it is never followed.
-    out.sah_cost8 = cost;
+    out.sah_cost = cost;
 }
 
 } // namespace
@@ -580,7 +614,7 @@ void build_bvh(const BuildTri* tris_in, size_t n_in, const BvhBuildOptions& opt_
     Builder b;
     b.opt = opt_in;
     if (b.opt.max_leaf < 1) b.opt.max_leaf = 1;
-    if (b.opt.max_leaf > RT_DEV_MAX_LEAF_TRIS) b.opt.max_leaf = RT_DEV_MAX_LEAF_TRIS; // leaf offsets inside a node are 4-bit: 3 * 4 <= 15
+    if (b.opt.max_leaf > RT_DEV_LEAF_STRIDE) b.opt.max_leaf = RT_DEV_LEAF_STRIDE; // a leaf owns RT_DEV_LEAF_STRIDE triangle records
     if (b.opt.max_depth > RT_DEV_MAX_BVH_DEPTH) b.opt.max_depth = RT_DEV_MAX_BVH_DEPTH;
     int hw = (int)std::thread::hardware_concurrency();
     b.max_tasks = std::max(1, (b.opt.threads > 0 ? b.opt.threads : (hw > 0 ? hw : 1)) - 1);
@@ -619,243 +653,7 @@ void build_bvh(const BuildTri* tris_in, size_t n_in, const BvhBuildOptions& opt_
     }
 #endif
 
-    // the 8-wide variant is emitted from a copy of the binary tree on its own thread while this one emits the 4-wide tree
-    // (both collapses merge small subtrees into leaves in place); it writes nodes8 / tris8 / depth8 / sah_cost8 only
-    std::future<void> wide8_done;
-    if (opt_in.wide8)
-        wide8_done = std::async(std::launch::async, [&, nodes_copy = std::vector<TmpNode>(b.nodes.begin(), b.nodes.begin() + b.next_node.load()), ids_copy = b.ids,
-                                                     n_nodes = b.next_node.load(), root, max_leaf = b.opt.max_leaf]() mutable {
-            collapse8(std::move(nodes_copy), std::move(ids_copy), n_nodes, root, tris_in, b.opt, max_leaf, out);
-        });
-    struct Join {
-        std::future<void>& f;
-        ~Join() {
-            if (f.valid()) f.get();
-        }
-    } join_wide8{wide8_done};
-
-    // ---- collapse to a 4-wide tree and emit it in the quantised layout ----
-    out.tris.resize(n);
-    size_t tri_cursor = 0;
-    auto is_leaf = [&](uint32_t t) { return b.nodes[t].left == 0xFFFFFFFFu; };
-    auto emit_leaf_tris = [&](const TmpNode& t) { // returns the first slot
-        size_t first = tri_cursor;
-        for (uint32_t i = 0; i < t.count; i++) put_tri(tris_in[b.ids[t.start + i]], &out.tris[tri_cursor++]);
-        out.tris[first].leaf_count = t.count; // the leaf test reads the run length from the first record
-        return (uint32_t)first;
-    };
-    const TmpNode& rt_node = b.nodes[root];
-    if (is_leaf(root)) { // whole scene fits one leaf
-        uint32_t first = emit_leaf_tris(rt_node);
-        out.root_ref = RT_DEV_LEAF_FLAG | first;
-        out.n_leaves = 1;
-        out.depth = 0;
-        return;
-    }
-#if RT_BVH_COLLAPSE_DP
-    // ---- which binary nodes become 4-wide nodes, which are absorbed, which subtrees become one leaf: chosen by dynamic
-    // programming over the binary tree (minimum expected cost; the greedy rule "open the child with the largest area"
-    // is the #else branch).  c[k-1] = cheapest cost of a subtree when it may occupy at most k child slots of its wide
-    // parent: k = 1: either one leaf (<= max_leaf triangles) or a wide node of its own, area * cost_traverse + the best
-    // split of 4 slots between its two children; k > 1: the best split of k slots between its children, or k - 1 slots.
-    struct Dp {
-        float c[4];
-        uint8_t split[4]; // [k-1]: slots given to the left child when k are distributed (0: use k - 1 slots instead); [0]: the split of 4 when the node is a wide node
-        uint8_t leaf;     // k = 1: the subtree is cheapest as a single leaf
-    };
-    std::vector<Dp> dp(b.next_node.load());
-    std::vector<uint32_t> sub_start(b.next_node.load(), 0), sub_count(b.next_node.load(), 0);
-    {
-        struct Frame {
-            uint32_t node;
-            int phase;
-        };
-        std::vector<Frame> st;
-        st.push_back({root, 0});
-        const float inf = std::numeric_limits<float>::infinity();
-        while (!st.empty()) {
-            Frame f = st.back();
-            st.pop_back();
-            const TmpNode& t = b.nodes[f.node];
-            Dp& d = dp[f.node];
-            if (t.left == 0xFFFFFFFFu) {
-                const float lc = opt_in.cost_intersect * (float)t.count * t.box.half_area();
-                for (int k = 0; k < 4; k++) d.c[k] = lc, d.split[k] = 0;
-                d.leaf = 1;
-                sub_start[f.node] = t.start;
-                sub_count[f.node] = t.count;
-                continue;
-            }
-            if (f.phase == 0) {
-                st.push_back({f.node, 1});
-                st.push_back({t.left, 0});
-                st.push_back({t.right, 0});
-                continue;
-            }
-            // after the insertion-based optimisation a subtree's triangles need not be one contiguous range of ids any
-            // more: only subtrees that still are may be merged into a leaf
-            const uint32_t ls = sub_start[t.left], lc_ = sub_count[t.left], rs = sub_start[t.right], rc_ = sub_count[t.right];
-            const bool contiguous = lc_ && rc_ && (ls + lc_ == rs || rs + rc_ == ls);
-            sub_start[f.node] = contiguous ? std::min(ls, rs) : 0;
-            sub_count[f.node] = contiguous ? lc_ + rc_ : 0;
-            const Dp &dl = dp[t.left], &dr = dp[t.right];
-            float dist[5] = {inf, inf, inf, inf, inf};
-            uint8_t arg[5] = {0, 0, 0, 0, 0};
-            for (int k = 2; k <= 4; k++)
-                for (int i = 1; i < k; i++) {
-                    const float v = dl.c[i - 1] + dr.c[k - i - 1];
-                    if (v < dist[k]) dist[k] = v, arg[k] = (uint8_t)i;
-                }
-            const float area = t.box.half_area();
-            const float wide = opt_in.cost_traverse * area + dist[4];
-            const uint32_t cnt = sub_count[f.node];
-            const float leafc = cnt && cnt <= b.opt.max_leaf ? opt_in.cost_intersect * (float)cnt * area : inf;
-            d.leaf = leafc <= wide ? 1 : 0;
-            d.c[0] = std::min(leafc, wide);
-            d.split[0] = arg[4];
-            for (int k = 2; k <= 4; k++) {
-                if (dist[k] < d.c[k - 2]) d.c[k - 1] = dist[k], d.split[k - 1] = arg[k];
-                else d.c[k - 1] = d.c[k - 2], d.split[k - 1] = 0;
-            }
-        }
-    }
-    // the children of a wide node: m's subtree in at most k slots
-    std::function<void(uint32_t, int, uint32_t*, int&)> expand = [&](uint32_t m, int k, uint32_t* ch, int& nch) {
-        TmpNode& t = b.nodes[m];
-        if (t.left != 0xFFFFFFFFu) {
-            while (k > 1 && dp[m].split[k - 1] == 0) k--;
-            if (k > 1) {
-                const int i = dp[m].split[k - 1];
-                expand(t.left, i, ch, nch);
-                expand(t.right, k - i, ch, nch);
-                return;
-            }
-            if (dp[m].leaf) { // the whole subtree as one leaf: its ids are one range, put them in index order
-                t.start = sub_start[m];
-                t.count = sub_count[m];
-                std::sort(b.ids.begin() + t.start, b.ids.begin() + t.start + t.count,
-                          [&](uint32_t x, uint32_t y) { return tris_in[x].prim_id < tris_in[y].prim_id; });
-                t.left = t.right = 0xFFFFFFFFu;
-            }
-        }
-        ch[nch++] = m;
-    };
-#endif
-    struct Item {
-        uint32_t tmp, dev, depth;
-    };
-    std::vector<Item> stack;
-    out.nodes.reserve(n / 2 + 1);
-    out.nodes.emplace_back();
-    stack.push_back({root, 0, 1});
-    double cost = 0.0;
-    const float root_area = rt_node.box.half_area();
-    while (!stack.empty()) {
-        Item it = stack.back();
-        stack.pop_back();
-        out.depth = std::max(out.depth, it.depth);
-        const TmpNode& t = b.nodes[it.tmp];
-#if RT_BVH_COLLAPSE_DP
-        uint32_t ch[4] = {0, 0, 0, 0};
-        int nch = 0;
-        {
-            const int i = dp[it.tmp].split[0];
-            expand(t.left, i, ch, nch);
-            expand(t.right, 4 - i, ch, nch);
-        }
-        while (false) {
-#else
-        // open the child with the largest surface area until the node has four children
-        uint32_t ch[4] = {t.left, t.right, 0, 0};
-        int nch = 2;
-        while (nch < 4) {
-#endif
-            int best = -1;
-            float best_area = -1.0f;
-            for (int c = 0; c < nch; c++)
-                if (!is_leaf(ch[c]) && b.nodes[ch[c]].box.half_area() > best_area) {
-                    best_area = b.nodes[ch[c]].box.half_area();
-                    best = c;
-                }
-            if (best < 0) break;
-            uint32_t open = ch[best];
-            ch[best] = b.nodes[open].left;
-            ch[nch++] = b.nodes[open].right;
-        }
-        // inner children first, then leaves (the kernel derives child kinds from the two counts)
-        uint32_t ordered[4];
-        int n_inner = 0, k = 0;
-        for (int c = 0; c < nch; c++)
-            if (!is_leaf(ch[c])) ordered[k++] = ch[c];
-        n_inner = k;
-        for (int c = 0; c < nch; c++)
-            if (is_leaf(ch[c])) ordered[k++] = ch[c];
-        const uint32_t node_base = (uint32_t)out.nodes.size();
-        for (int c = 0; c < n_inner; c++) out.nodes.emplace_back();
-        const uint32_t tri_base = (uint32_t)tri_cursor;
-        uint32_t child_off = 0; // 4 bits per child slot: i for inner child i, first triangle - tri_base for a leaf
-        for (int c = 0; c < n_inner; c++) child_off |= (uint32_t)c << (4 * c);
-        for (int c = n_inner; c < nch; c++) {
-            const TmpNode& lf = b.nodes[ordered[c]];
-            const uint32_t first = emit_leaf_tris(lf);
-            child_off |= ((first - tri_base) & 15u) << (4 * c);
-            out.n_leaves++;
-            if (root_area > 0) cost += opt_in.cost_intersect * lf.count * lf.box.half_area() / root_area;
-        }
-        for (int c = n_inner - 1; c >= 0; c--) stack.push_back({ordered[c], node_base + (uint32_t)c, it.depth + 1});
-        if (root_area > 0) cost += opt_in.cost_traverse * t.box.half_area() / root_area;
-
-        // quantise the children's boxes on a per-node grid: plane = org + q * 2^(e-127), q in [0,255], rounded outward
-        DevNode4& d = out.nodes[it.dev];
-        uint32_t ex[3];
-        for (int a = 0; a < 3; a++) {
-            d.org[a] = t.box.mn[a];
-            double extent = (double)t.box.mx[a] - (double)t.box.mn[a];
-            int e = 1; // 2^-126: every plane coincides with the origin
-            if (extent > 0.0) {
-                int fe;
-                std::frexp(extent / 255.0, &fe); // extent/255 = m * 2^fe, m in [0.5,1)  =>  2^fe >= extent/255
-                e = fe + 127;
-                if (e < 1) e = 1;
-                if (e > 254) e = 254;
-            }
-            ex[a] = (uint32_t)(e - 127) & 0xFFu; // stored as a signed byte k: plane = org + q * 2^k
-            const double scale = std::ldexp(1.0, e - 127);
-            uint32_t lo_word = 0, hi_word = 0;
-            for (int c = 0; c < 4; c++) {
-                uint32_t qlo = 255, qhi = 0; // absent child: inverted, never hit
-                if (c < nch) {
-                    const Box& cb = b.nodes[ordered[c]].box;
-                    double lo = std::floor(((double)cb.mn[a] - (double)d.org[a]) / scale);
-                    double hi = std::ceil(((double)cb.mx[a] - (double)d.org[a]) / scale);
-                    lo = std::min(std::max(lo, 0.0), 255.0);
-                    hi = std::min(std::max(hi, 0.0), 255.0);
-                    while (lo > 0.0 && (double)d.org[a] + lo * scale > (double)cb.mn[a]) lo -= 1.0;
-                    while (hi < 255.0 && (double)d.org[a] + hi * scale < (double)cb.mx[a]) hi += 1.0;
-#ifdef RT_BVH_EXTRA_INFLATE /* measurement only: what does one more grid step of inflation per side cost? */
-                    lo = std::max(lo - RT_BVH_EXTRA_INFLATE, 0.0);
-                    hi = std::min(hi + RT_BVH_EXTRA_INFLATE, 255.0);
-#endif
-                    qlo = (uint32_t)lo;
-                    qhi = (uint32_t)hi;
-                }
-                lo_word |= qlo << (8 * c);
-                hi_word |= qhi << (8 * c);
-            }
-            d.qlo[a] = lo_word;
-            d.qhi[a] = hi_word;
-        }
-        d.ex_off = ex[0] | (ex[1] << 8) | (ex[2] << 16) | ((child_off & 0xFFu) << 24);
-        d.base_off = (node_base & RT_DEV_NODE_BASE_MASK) | ((child_off >> 8) << 24);
-        // Absent child slots (inverted boxes) decode to `LEAF | tri_base + 0`.  They are never entered as long as the float
-        // evaluation can tell 255 grid steps apart, which fails for a degenerate node (all extents zero) or a ray origin
-        // ~1e8 grid steps away; make that case harmless: the reference must then still name a real leaf (the node's first
-        // leaf, or triangle 0 — always the start of a leaf — when it has none): a redundant triangle test, never a bad read.
-        const uint32_t safe_tri_base = n_inner < nch ? tri_base : 0u;
-        d.tri_inf = (safe_tri_base & RT_DEV_TRI_BASE_MASK) | ((uint32_t)n_inner << 27);
-    }
-    out.root_ref = 0;
-    out.sah_cost = cost;
+    collapse8(b.nodes, b.ids, b.next_node.load(), root, tris_in, b.opt, b.opt.max_leaf, out);
 }
 
 } // namespace rt

@@ -155,10 +155,13 @@ __device__ __forceinline__ bool test_leaf(const DevTri* __restrict__ tris, uint3
 // ------------------------------------------------------------------------------------
 // BVH traversal.  Replaces BvhTraverser::traverse_and_intersect (shader/src/bvh.rs:18-88) and
 // ray_aabb_intersect (shader/src/intersection.rs:151-164): per-lane depth-first walk over the
-// 4-wide quantised tree of device_layout.h.  A visit fetches one 48-byte node (3 x dwordx4),
-// slab-tests its (up to) four children, continues with the nearest hit child and pushes the others
-// far-to-near.  Children whose entry distance exceeds the closest hit are skipped (the reference's
-// slab test ignores the closest hit and so visits a superset: result-neutral).
+// 8-wide quantised tree of device_layout.h.  A visit fetches one 80-byte node (5 x dwordx4) and
+// slab-tests its (up to) eight children; the result is an 8-bit mask of the slots the ray enters.
+// Children whose entry distance exceeds the closest hit are skipped (the reference's slab test
+// ignores the closest hit and so visits a superset: result-neutral).  The children entered are
+// visited in increasing (slot XOR ray octant) - the builder puts a child into the slot that names
+// the corner of the node it lies toward - so there is no distance sort, and what remains of a node
+// is a (base, mask) GROUP: one 64-bit stack entry per visit.
 //
 // The boxes are FILTERS only — which primitive is hit is decided by the reference's
 // Möller–Trumbore arithmetic — so they may be conservative but must never be too small, and "too
@@ -166,23 +169,17 @@ __device__ __forceinline__ bool test_leaf(const DevTri* __restrict__ tris, uint3
 // that grazes an edge can be accepted by the triangle test while missing the exact box by rounding.
 // The quantised planes are rounded outward by the builder; the float evaluation here is widened:
 // with a = scale/d, b = (org - o)/d the plane distances are fma(q, a, b), whose own absolute error
-// is below 2^-22 * (|org - o| + 255 * scale) / |d| (one rounding each in org - o, a, b, 1/d and the
-// fma).  Near planes are moved back and far planes forward by RT_FILTER_SLACK (1e-6, four times that
-// bound) times the same magnitude; the margin is there for the triangle test's own rounding.  All parity
-// tests (up to 3.8 M triangles, bit-exact against brute-force / mesh-order oracles) pass with it.
-//
-// The stack lives in LDS, lane-interleaved (entry k of lane l at stack[k * 64 + l]): ds_read /
-// ds_write_b32 with consecutive lanes on consecutive banks.  A visit pushes at most 3 entries, the
-// launch provides 3 * depth + 1 entries per lane (DevScene::stack_entries), so it cannot overflow.
+// is below (2^-22 + 2^-23) * (|org - o| + 255 * scale) / |d| (one rounding each in org - o, a, b and the
+// fma, one ulp in v_rcp_f32).  Near planes are moved back and far planes forward by RT_FILTER_SLACK
+// (1e-6, 2.8 times that bound) times the same magnitude; the margin is there for the triangle test's
+// own rounding.  All parity tests (up to 3.8 M triangles, bit-exact against brute-force / mesh-order
+// oracles, adversarial scales and origins) pass with it.
 // ------------------------------------------------------------------------------------
 #ifndef RT_FILTER_SLACK
 #define RT_FILTER_SLACK 1.0e-6f
 #endif
-#ifndef RT_EXPERIMENT_NO_WIDENING
-#define RT_EXPERIMENT_NO_WIDENING 0 /* measurement only */
-#endif
 #ifndef RT_FILTER_RCP
-#define RT_FILTER_RCP 1 /* round 2: -1 % on the headline frame with both trees; the filter's error bound is derived below */
+#define RT_FILTER_RCP 1 /* round 2: -1 % on the headline frame; the error bound above includes its one ulp */
 #endif
 struct FilterRay { // per-segment constants of the box filter
     V3 o, inv;     // inv = 1/d with |d| clamped away from zero (a filter may do that; the triangle test uses the real d)
@@ -194,153 +191,31 @@ __device__ __forceinline__ FilterRay make_filter_ray(V3 o, V3 d) {
     float dy = fabsf(d.y) < 1e-30f ? copysignf(1e-30f, d.y) : d.y;
     float dz = fabsf(d.z) < 1e-30f ? copysignf(1e-30f, d.z) : d.z;
 #if RT_FILTER_RCP
-    // v_rcp_f32 (1 ulp) instead of three IEEE divisions (~11 instructions each): the filter's error bound grows
-    // from 2^-22 to 2^-22 + 2^-23 relative, still far inside RT_FILTER_SLACK
     f.inv = v3(__builtin_amdgcn_rcpf(dx), __builtin_amdgcn_rcpf(dy), __builtin_amdgcn_rcpf(dz));
 #else
     f.inv = v3(1.0f / dx, 1.0f / dy, 1.0f / dz);
 #endif
     return f;
 }
-
-// Per-lane stack access.  LDS_N == 0: every entry lives in LDS (lane-interleaved).  LDS_N > 0: entries below LDS_N
-// live in LDS, deeper ones in a global overflow area (also lane-interleaved): measured on the sponza-like and
-// bistro-like scenes the stack never exceeds 20 entries and is deeper than 16 in < 0.001 % of the visits, so a
-// short LDS part costs ~4 KB per wave instead of (3 * depth + 4) * 256 B and more than doubles the waves per CU.
-// Callers test wave-wide whether any lane is near the LDS limit and take the branch-free LDS-only path if none is.
-template <int LDS_N>
-__device__ __forceinline__ void stack_store(uint32_t* __restrict__ lds, uint32_t* __restrict__ ovf, int k, uint32_t v) {
-    if (LDS_N == 0 || k < LDS_N) lds[k * WAVE] = v;
-    else ovf[(k - LDS_N) * WAVE] = v;
+// (dx < 0) | (dy < 0) << 1 | (dz < 0) << 2: children are visited in increasing (slot XOR octant)
+__device__ __forceinline__ uint32_t ray_octant(const FilterRay& f) {
+    return (f.inv.x < 0.0f ? 1u : 0u) | (f.inv.y < 0.0f ? 2u : 0u) | (f.inv.z < 0.0f ? 4u : 0u);
 }
-template <int LDS_N>
-__device__ __forceinline__ uint32_t stack_load(const uint32_t* __restrict__ lds, const uint32_t* __restrict__ ovf, int k) {
-    if (LDS_N == 0 || k < LDS_N) return lds[k * WAVE];
-    return ovf[(k - LDS_N) * WAVE];
-}
-// pop for a whole wave: `sp` already decremented in the lanes where `want` holds
-template <int LDS_N>
-__device__ __forceinline__ uint32_t stack_pop(const uint32_t* __restrict__ lds, const uint32_t* __restrict__ ovf, int sp) {
-    if (LDS_N == 0 || __ballot(sp >= LDS_N) == 0ull) return lds[sp * WAVE];
-    return stack_load<LDS_N>(lds, ovf, sp);
+// The set slot of the 8-bit mask m (!= 0) with the smallest (slot XOR oct): permute the mask so that bit j holds slot
+// j XOR oct (three conditional swaps), take the lowest set bit.  The persistent kernels of wavefront.hip read the same
+// function from a 2 KB table in LDS instead (tests compare the kernels bit for bit).
+__device__ __forceinline__ uint32_t first_slot(uint32_t m, uint32_t oct) {
+    uint32_t p = m & 0xFFu;
+    if (oct & 1u) p = ((p & 0x55u) << 1) | ((p >> 1) & 0x55u);
+    if (oct & 2u) p = ((p & 0x33u) << 2) | ((p >> 2) & 0x33u);
+    if (oct & 4u) p = ((p & 0x0Fu) << 4) | (p >> 4);
+    return ((uint32_t)__ffs((int)p) - 1u) ^ oct;
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-#define RT_KEY_MASK 0x7FFFFFFCu /* entry distance (non-negative float bits) with the two low mantissa bits replaced by the child slot */
-#define RT_KEY_MISS 0x7F7FFFFCu /* F32_MAX & RT_KEY_MASK: keys at or above it are children the ray does not enter */
-#define RT_KEY_SORT2(a, b)            \
-    {                                 \
-        const uint32_t lo_ = min(a, b); \
-        b = max(a, b);                \
-        a = lo_;                      \
-    }
 
-// One visit of inner node `cur`.  Updates cur / the stack; returns false when the walk is exhausted.
-template <bool COUNT, int LDS_N = 0>
-__device__ __forceinline__ bool visit_node4(const uint4* __restrict__ nodes, const FilterRay& fr, float closest_t, uint32_t* __restrict__ stack,
-                                            int& sp, uint32_t& cur, Counts& cnt, uint32_t* __restrict__ ovf = nullptr) {
-    const uint4* n = nodes + (size_t)cur * 3;
-    const uint4 w0 = n[0], w1 = n[1], w2 = n[2];
-    if (COUNT) cnt.nodes++;
-    // grid scale 2^k per axis, k a signed byte: a = scale / d as one ldexp of the ray's reciprocal (exact)
-    const float ax = ldexpf(fr.inv.x, (int)(int8_t)(w0.w & 0xFFu)), ay = ldexpf(fr.inv.y, (int)(int8_t)((w0.w >> 8) & 0xFFu)),
-                az = ldexpf(fr.inv.z, (int)(int8_t)((w0.w >> 16) & 0xFFu));
-    const float dox = __uint_as_float(w0.x) - fr.o.x, doy = __uint_as_float(w0.y) - fr.o.y, doz = __uint_as_float(w0.z) - fr.o.z;
-    const float bx = dox * fr.inv.x, by = doy * fr.inv.y, bz = doz * fr.inv.z;
-    // widening per axis: RT_FILTER_SLACK * (|b| + 255 |a|), see above.  It stays per axis: a ray almost parallel to an
-    // axis has an enormous |b| (and error bound) on that axis only; one bound for the whole interval test
-    // (tmin - 2E <= tmax, E summed over the axes) is 5 instructions cheaper and 26 % slower because the degenerate axis
-    // inflates every box.  Without any widening the frame is 3.7 % faster (RT_EXPERIMENT_NO_WIDENING; not conservative).
-    const float ex = fmaf(255.0f, fabsf(ax), fabsf(bx)) * RT_FILTER_SLACK;
-    const float ey = fmaf(255.0f, fabsf(ay), fabsf(by)) * RT_FILTER_SLACK;
-    const float ez = fmaf(255.0f, fabsf(az), fabsf(bz)) * RT_FILTER_SLACK;
-    // (near, far) pairs (b - e, b + e) as one packed fma each; then one packed fma per child and axis
-#if RT_EXPERIMENT_NO_WIDENING
-    const f32x2 bx2 = {bx, bx}, by2 = {by, by}, bz2 = {bz, bz};
-    (void)ex; (void)ey; (void)ez;
-#else
-    const f32x2 pm = {-1.0f, 1.0f};
-    const f32x2 bx2 = __builtin_elementwise_fma((f32x2){ex, ex}, pm, (f32x2){bx, bx});
-    const f32x2 by2 = __builtin_elementwise_fma((f32x2){ey, ey}, pm, (f32x2){by, by});
-    const f32x2 bz2 = __builtin_elementwise_fma((f32x2){ez, ez}, pm, (f32x2){bz, bz});
-#endif
-    const f32x2 ax2 = {ax, ax}, ay2 = {ay, ay}, az2 = {az, az};
-    // entry planes are the lower ones along axes the ray travels in +, the upper ones otherwise
-    const bool px = fr.inv.x >= 0.0f, py = fr.inv.y >= 0.0f, pz = fr.inv.z >= 0.0f;
-    const uint32_t nxw = px ? w1.z : w2.y, fxw = px ? w2.y : w1.z; // w1.z qlo_x, w2.y qhi_x
-    const uint32_t nyw = py ? w1.w : w2.z, fyw = py ? w2.z : w1.w; // w1.w qlo_y, w2.z qhi_y
-    const uint32_t nzw = pz ? w2.x : w2.w, fzw = pz ? w2.w : w2.x; // w2.x qlo_z, w2.w qhi_z
-    const float limit = closest_t * 1.0000153f; // culling with slack, so equal-t candidates are still visited
-    uint32_t k[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const f32x2 qx = {(float)((nxw >> (8 * i)) & 0xFFu), (float)((fxw >> (8 * i)) & 0xFFu)};
-        const f32x2 qy = {(float)((nyw >> (8 * i)) & 0xFFu), (float)((fyw >> (8 * i)) & 0xFFu)};
-        const f32x2 qz = {(float)((nzw >> (8 * i)) & 0xFFu), (float)((fzw >> (8 * i)) & 0xFFu)};
-        const f32x2 tx = __builtin_elementwise_fma(qx, ax2, bx2);
-        const f32x2 ty = __builtin_elementwise_fma(qy, ay2, by2);
-        const f32x2 tz = __builtin_elementwise_fma(qz, az2, bz2);
-        const float tmin = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, 0.0f));
-        const float tmax = fminf(fminf(tx.y, ty.y), fminf(tz.y, limit));
-        const float t = (tmin <= tmax) ? tmin : RT_F32_MAX; // absent children are inverted boxes: never entered
-        k[i] = (__float_as_uint(t) & RT_KEY_MASK) | (uint32_t)i;
-    }
-    // keep the node's three 16-byte loads together (the reference words are only used after the sort; without
-    // this the compiler sinks their load into the branch below, a fourth and dependent fetch)
-    uint32_t w1x = w1.x, w1y = w1.y;
-    asm volatile("" : "+v"(w1x), "+v"(w1y));
-    // sort the four keys: children the ray does not enter end up last.  (The order among children whose entry
-    // distances agree to 2 ulp is arbitrary: result-neutral, ties between HITS are resolved by triangle index.)
-    uint32_t k0 = k[0], k1 = k[1], k2 = k[2], k3 = k[3];
-    RT_KEY_SORT2(k0, k1)
-    RT_KEY_SORT2(k2, k3)
-    RT_KEY_SORT2(k0, k2)
-    RT_KEY_SORT2(k1, k3)
-    RT_KEY_SORT2(k1, k2)
-    if (k0 >= RT_KEY_MISS) { // nothing entered: continue with the stack
-        if (sp == 0) return false;
-        sp--;
-        cur = stack_pop<LDS_N>(stack, ovf, sp);
-        return true;
-    }
-    // child references from the sorted slots: base + 4-bit offset
-    const uint32_t child_off = (w0.w >> 24) | ((w1x >> 16) & 0xFF00u);
-    const uint32_t base_inner = w1x & RT_DEV_NODE_BASE_MASK;
-    const uint32_t base_leaf = (w1y & RT_DEV_TRI_BASE_MASK) | RT_DEV_LEAF_FLAG;
-    const uint32_t n_inner4 = (w1y >> 25) & 0x1Cu; // 4 * n_inner
-#define RT_CHILD_REF(key, out)                                                            \
-    {                                                                                     \
-        const uint32_t sh_ = ((key) << 2) & 12u;                                          \
-        out = (sh_ < n_inner4 ? base_inner : base_leaf) + ((child_off >> sh_) & 15u);     \
-    }
-    // push the other entered children far-to-near without branching: always store three words (the launch
-    // provides three spare entries), advance the pointer by the number of real ones
-    const int extra = (k1 < RT_KEY_MISS ? 1 : 0) + (k2 < RT_KEY_MISS ? 1 : 0) + (k3 < RT_KEY_MISS ? 1 : 0);
-    const uint32_t ek0 = extra == 3 ? k3 : (extra == 2 ? k2 : k1);
-    const uint32_t ek1 = extra == 3 ? k2 : k1;
-    uint32_t r0, e0, e1, r1;
-    RT_CHILD_REF(k0, r0)
-    RT_CHILD_REF(ek0, e0)
-    RT_CHILD_REF(ek1, e1)
-    RT_CHILD_REF(k1, r1)
-#undef RT_CHILD_REF
-    cur = r0;
-    if (LDS_N == 0 || __ballot(sp + 3 > LDS_N) == 0ull) {
-        stack[sp * WAVE] = e0;
-        stack[(sp + 1) * WAVE] = e1;
-        stack[(sp + 2) * WAVE] = r1;
-    } else {
-        stack_store<LDS_N>(stack, ovf, sp, e0);
-        stack_store<LDS_N>(stack, ovf, sp + 1, e1);
-        stack_store<LDS_N>(stack, ovf, sp + 2, r1);
-    }
-    sp += extra;
-    return true;
-}
-
-// One visit of the 8-wide node `idx` (DevNode8, device_layout.h): the same conservative quantised-box filter as
-// visit_node4 for eight slots, but no sort: the result is the 8-bit mask of the slots the ray enters (bit s = slot s);
-// the caller visits them in increasing (slot XOR ray octant).  Returns the mask, already restricted to occupied slots.
+// One visit of the 8-wide node `idx` (DevNode8, device_layout.h): the conservative quantised-box filter for eight slots.
+// Returns the 8-bit mask of the slots the ray enters (bit s = slot s), already restricted to occupied slots.
 template <bool COUNT>
 __device__ __forceinline__ uint32_t visit_node8(const uint4* __restrict__ nodes, uint32_t idx, const FilterRay& fr, float closest_t, Counts& cnt,
                                                 uint32_t& child_base, uint32_t& tri_base, uint32_t& imask, uint32_t& lmask) {
@@ -392,30 +267,51 @@ __device__ __forceinline__ uint32_t visit_node8(const uint4* __restrict__ nodes,
     return ~miss & (imask | lmask);
 }
 
-// ANY_HIT (shadow segments of the extended mode): return at the first accepted triangle.
+// The walk of one lane on its own (reference-mode kernel, nested-loop megakernel): groups on a per-lane stack of 64-bit
+// entries (lane-interleaved: entry k of this lane at stack[k * 64]), a node's leaves tested right after its visit, before its
+// inner children (their hits cull the children's subtrees).  ANY_HIT (shadow segments of the extended mode): return at the
+// first accepted triangle.
 template <bool COUNT, bool ANY_HIT>
-__device__ __forceinline__ void traverse(const DevScene& sc, V3 o, V3 d, uint32_t* __restrict__ stack, Hit& hit, Counts& cnt) {
-    if (sc.n_tris == 0) return;
+__device__ __forceinline__ void traverse(const DevScene& sc, V3 o, V3 d, uint2* __restrict__ stack, Hit& hit, Counts& cnt) {
+    if (sc.n_nodes == 0) return;
     const FilterRay fr = make_filter_ray(o, d);
+    const uint32_t oct = ray_octant(fr);
     const uint4* __restrict__ nodes = reinterpret_cast<const uint4*>(sc.nodes);
-    uint32_t cur = sc.root_ref;
+    uint32_t g_base = 0, g_bits = 1u | (1u << 8); // the root as the only child of a group
     int sp = 0;
     for (;;) {
-        if (!(cur & RT_DEV_LEAF_FLAG)) {
-            if (!visit_node4<COUNT>(nodes, fr, hit.t, stack, sp, cur, cnt)) break;
-            continue;
+        if ((g_bits & 0xFFu) == 0u) {
+            if (sp == 0) break;
+            sp--;
+            const uint2 e = stack[sp * WAVE];
+            g_base = e.x;
+            g_bits = e.y;
         }
-        if (test_leaf<COUNT, ANY_HIT>(sc.tris, cur, o, d, hit, cnt)) return;
-        if (sp == 0) break;
-        sp--;
-        cur = stack[sp * WAVE];
+        const uint32_t i = first_slot(g_bits, oct);
+        g_bits ^= 1u << i;
+        const uint32_t node = g_base + (uint32_t)__popc(__builtin_amdgcn_ubfe(g_bits, 8u, i)); // inner slots below i
+        if (g_bits & 0xFFu) {
+            stack[sp * WAVE] = make_uint2(g_base, g_bits);
+            sp++;
+        }
+        uint32_t cb, tb, im, lm;
+        const uint32_t hm = visit_node8<COUNT>(nodes, node, fr, hit.t, cnt, cb, tb, im, lm);
+        uint32_t t = hm & lm;
+        while (t) {
+            const uint32_t sl = first_slot(t, oct);
+            t ^= 1u << sl;
+            const uint32_t first = tb + RT_DEV_LEAF_STRIDE * (uint32_t)__popc(lm & ((1u << sl) - 1u));
+            if (test_leaf<COUNT, ANY_HIT>(sc.tris, RT_DEV_LEAF_FLAG | first, o, d, hit, cnt)) return;
+        }
+        g_base = cb;
+        g_bits = (hm & im) | (im << 8);
     }
 }
 
 // find_closest_intersection (shader/src/lib.rs:174-249): spheres first, then triangles with
 // max_t = sphere t; a triangle is only accepted strictly closer, so it wins when both hit.
 template <bool COUNT>
-__device__ __forceinline__ Hit find_closest(const DevScene& sc, V3 o, V3 d, uint32_t* stack, Counts& cnt) {
+__device__ __forceinline__ Hit find_closest(const DevScene& sc, V3 o, V3 d, uint2* stack, Counts& cnt) {
     Hit hit;
     hit.t = RT_F32_MAX; // f32::MAX - 2.0 == f32::MAX
     hit.prim = RT_PRIM_MISS;

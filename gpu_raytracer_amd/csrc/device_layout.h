@@ -5,12 +5,10 @@
 // triangle through three dependent gathers: index -> Triangle -> 3 x Vertex = 56 bytes
 // (shader/src/bvh.rs:113-122, triangle_access.rs:26-47).  Here:
 //
-//   DevNode4 48 B, one per INNER node of a 4-wide BVH: the boxes of up to four children,
+//   DevNode8 80 B, one per INNER node of an 8-wide BVH: the boxes of up to eight children,
 //            quantised to 8 bits per plane on a per-node grid (origin + power-of-two scale per
-//            axis, boxes rounded outward), plus two base indices.  One visit = 3 x dwordx4 and
-//            replaces two to three visits of a binary tree.  Measured reason: the
-//            traversal is bound by vector-memory instructions per segment, so fewer and narrower
-//            node fetches are what pays.  Quantised boxes are supersets of the exact ones: they
+//            axis, boxes rounded outward).  One visit = 5 x dwordx4 and replaces three to four
+//            visits of a binary tree.  Quantised boxes are supersets of the exact ones: they
 //            only filter, every hit is decided by the triangle test, results are unchanged.
 //            Leaves have no node record: a leaf is a run of the triangle array (length in its first record).
 //   DevTri   48 B, pre-gathered (v0, e1 = v1-v0, e2 = v2-v0, material, original
@@ -27,36 +25,17 @@
 #define RT_DEV_REF_NONE 0xFFFFFFFFu /* "nothing to visit" (a leaf reference no tree contains) */
 #define RT_DEV_MAX_LEAF_TRIS 4u
 #define RT_DEV_MAX_TRIS 0x07FFFFFFu
-#define RT_DEV_MAX_BVH_DEPTH 32 /* binary build depth bound; the 4-wide tree is at most this deep */
-/* A visit of a 4-wide node pushes at most 3 references, so a tree of depth D needs 3*D + 1 stack entries per lane.
-   The stack lives in dynamic LDS sized from the depth of the uploaded tree (DevScene::stack_entries). */
-#define RT_DEV_MAX_STACK_ENTRIES (3 * RT_DEV_MAX_BVH_DEPTH + 1)
+#define RT_DEV_MAX_BVH_DEPTH 32 /* binary build depth bound; the 8-wide tree is at most this deep */
+/* A visit parks at most two (base, mask) groups - the siblings still to visit and a postponed leaf group - so a tree of
+   depth D needs 2*D + 2 64-bit stack entries per lane (DevScene::stack_entries). */
+#define RT_DEV_MAX_STACK_ENTRIES (2 * RT_DEV_MAX_BVH_DEPTH + 2)
 
 #define RT_PRIM_MISS 0xFFFFFFFFu
 #define RT_PRIM_SPHERE_FLAG 0x80000000u
 
-// Traversal references (stack entries, root_ref): bit 31 clear = inner node index;
-// bit 31 set = leaf: RT_DEV_LEAF_FLAG | first triangle.  The number of triangles of a leaf is stored in its
-// first triangle record (DevTri::leaf_count), which the leaf test loads anyway.
-//
-// A child reference is `base + offset`: the visit sorts 4 keys (entry distance with the child slot in the two
-// low mantissa bits, 10 integer min/max) and only then turns the up-to-four slots it needs into references:
-// offset = 4-bit field `slot` of child_off, base = node_base for slots < n_inner, LEAF | tri_base for the others.
-struct DevNode4 { // 48 bytes, 16-byte aligned
-    float org[3];      // quantisation origin (the node's box minimum)
-    uint32_t ex_off;   // byte 0..2: signed exponent k of axis x,y,z (plane = org + q * 2^k, k in [-126, 127]); byte 3: offsets of child slots 0 (low nibble) and 1
-    uint32_t base_off; // bits 0..23 index of the first inner child (inner children are consecutive); byte 3: offsets of child slots 2 and 3
-    uint32_t tri_inf;  // bits 0..26 first triangle of the first leaf child (leaf children's triangles are consecutive, in child order); 27..29 n_inner
-    uint32_t qlo[3];   // [axis]: byte i = quantised lower plane of child i (children: inner ones first, then leaves)
-    uint32_t qhi[3];   // [axis]: byte i = quantised upper plane of child i; absent children are inverted (lo 255, hi 0)
-};
-// offset of child slot i: i for an inner child (node_base + i), the distance of a leaf's first triangle from tri_base otherwise (<= 12)
-#define RT_DEV_NODE_BASE_MASK 0x00FFFFFFu
-#define RT_DEV_MAX_NODES 0x00FFFFFFu
-#define RT_DEV_TRI_BASE_MASK 0x07FFFFFFu
-
-// 8-wide variant (experiment of round 2, after Ylitie, Karras, Laine, "Efficient Incoherent Ray Traversal on GPUs Through
-// Compressed Wide BVHs", 2017): 80 bytes = 5 x dwordx4, up to eight children in SLOTS chosen by the builder so that a
+// After Ylitie, Karras, Laine, "Efficient Incoherent Ray Traversal on GPUs Through Compressed Wide BVHs", 2017 (round 1 used a
+// 4-wide node with a 4-key distance sort; measured against it in round 2, profiles/ab_r02.json):
+// 80 bytes = 5 x dwordx4, up to eight children in SLOTS chosen by the builder so that a
 // child's slot number says toward which corner of the node it lies (bit a set: the high side of axis a).  A ray visits
 // the children it enters in increasing (slot XOR ray octant): no distance sort.  Inner children are consecutive nodes in
 // slot order (child = child_base + number of inner slots below it), every leaf child owns RT_DEV_LEAF_STRIDE consecutive
@@ -74,6 +53,7 @@ struct DevNode8 { // 80 bytes, 16-byte aligned
     uint32_t qhi[3][2];   // upper planes; empty slots are inverted (lo 255, hi 0)
 };
 #define RT_DEV_LEAF_STRIDE 4u
+#define RT_DEV_MAX_NODES 0x3FFFFFFFu
 
 struct DevTri { // 48 bytes, 16-byte aligned
     float v0[3];
@@ -113,23 +93,17 @@ struct DevLight { // 64 bytes: the 11 words of Light the kernel reads (shader/sr
 };
 
 struct DevScene {
-    const DevNode4* nodes;
-    const DevTri* tris;
+    const DevNode8* nodes;
+    const DevTri* tris; // RT_DEV_LEAF_STRIDE records per leaf, in the order of the nodes' leaf slots
     const DevSphere* spheres;
     const DevLight* lights;
     const DevMaterial* materials;
-    uint32_t n_nodes;
-    uint32_t n_tris;
+    uint32_t n_nodes; // 0: no triangles.  Otherwise node 0 is the root (a scene of one leaf gets a root with that one child)
+    uint32_t n_tris;  // triangle records incl. padding
     uint32_t n_spheres;
     uint32_t n_lights;
     uint32_t n_materials; // `materials.len()` of shader/src/lib.rs:307 := material_count
-    uint32_t root_ref;    // child reference of the root (a leaf reference for tiny scenes)
-    uint32_t stack_entries; // per-lane LDS stack entries the kernels must provide: 3 * depth + 1
-    // 8-wide experiment: its own node and triangle arrays (leaf order and padding differ)
-    const DevNode8* nodes8;
-    const DevTri* tris8;
-    uint32_t n_nodes8;
-    uint32_t stack_entries8; // 64-bit entries: at most 2 per level + 2
+    uint32_t stack_entries; // 64-bit stack entries per lane the kernels must provide: 2 * depth + 2
 };
 
 // Camera terms that do not depend on the pixel, computed once on the host in the

@@ -10,8 +10,8 @@
 //
 // Arithmetic that decides WHICH primitive is hit (ray generation, Möller–Trumbore,
 // sphere quadratic) and the shading keep the reference's f32 operation order; the file
-// is compiled with -ffp-contract=off so nothing is fused implicitly.  The slab test is
-// the reference's own test applied to our boxes plus culling by the closest hit.
+// is compiled with -ffp-contract=off so nothing is fused implicitly.  The boxes of the
+// 8-wide tree are a conservative filter (device_common.h); culling by the closest hit.
 #include "kernels.h"
 
 #include <algorithm>
@@ -30,10 +30,10 @@ namespace {
 // ------------------------------------------------------------------------------------
 template <bool COUNT>
 __global__ __launch_bounds__(WAVE) void k_render_reference(DevScene sc, DevFrame fr, DevTargets tg) {
-    extern __shared__ uint32_t s_stack[]; // DevScene::stack_entries * 64 words
+    extern __shared__ uint2 s_stack[]; // DevScene::stack_entries * 64 64-bit entries
     PixelCoord px = block_pixel(fr);
     if (!px.valid) return;
-    uint32_t* stack = s_stack + threadIdx.x;
+    uint2* stack = s_stack + threadIdx.x;
     Counts cnt = {0u, 0u};
     const bool wavefront = fr.mode != 0;
     V3 color = v3(0.0f, 0.0f, 0.0f);
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(WAVE) void k_render_reference(DevScene sc, DevFrame
 
 // any hit in (1e-5, tmax)?  Spheres first, then the BVH with early exit.
 template <bool COUNT>
-__device__ __forceinline__ bool occluded(const DevScene& sc, V3 o, V3 d, float tmax, uint32_t* stack, Counts& cnt) {
+__device__ __forceinline__ bool occluded(const DevScene& sc, V3 o, V3 d, float tmax, uint2* stack, Counts& cnt) {
     Hit h;
     h.t = tmax;
     h.prim = RT_PRIM_MISS;
@@ -81,7 +81,7 @@ __device__ __forceinline__ bool occluded(const DevScene& sc, V3 o, V3 d, float t
 
 template <bool COUNT>
 __device__ __forceinline__ V3 ext_direct(const DevScene& sc, const DevMaterial& m, V3 point, V3 normal, bool ambient, bool shadows,
-                                         uint32_t* stack, Counts& cnt, SegCounts& seg) {
+                                         uint2* stack, Counts& cnt, SegCounts& seg) {
     V3 total = v3(0.0f, 0.0f, 0.0f);
     if (ambient) total = total + ld3(m.albedo) * 0.1f;
     for (uint32_t li = 0; li < sc.n_lights; li++) {
@@ -103,7 +103,7 @@ __device__ __forceinline__ V3 ext_direct(const DevScene& sc, const DevMaterial& 
 
 template <bool COUNT>
 __device__ __forceinline__ V3 ext_trace_path(const DevScene& sc, const DevFrame& fr, uint32_t px, uint32_t py, uint32_t sample,
-                                             uint32_t* stack, Counts& cnt, SegCounts& seg) {
+                                             uint2* stack, Counts& cnt, SegCounts& seg) {
     SimpleRng rng = rng_for(fr.frame_seed + px + py * fr.width, sample);
     float jx = 0.5f, jy = 0.5f;
     if (fr.spp > 1) {
@@ -198,9 +198,9 @@ __device__ __forceinline__ V3 ext_trace_path(const DevScene& sc, const DevFrame&
 
 template <bool COUNT>
 __global__ __launch_bounds__(WAVE) void k_render_extended(DevScene sc, DevFrame fr, DevTargets tg) {
-    extern __shared__ uint32_t s_stack[]; // DevScene::stack_entries * 64 words
+    extern __shared__ uint2 s_stack[]; // DevScene::stack_entries * 64 64-bit entries
     PixelCoord px = block_pixel(fr);
-    uint32_t* stack = s_stack + threadIdx.x;
+    uint2* stack = s_stack + threadIdx.x;
     Counts cnt = {0u, 0u};
     SegCounts seg = {0u, 0u, 0u};
     if (px.valid) {
@@ -249,13 +249,6 @@ __global__ __launch_bounds__(WAVE) void k_render_extended(DevScene sc, DevFrame 
 #ifndef RT_SM_MIN_WAVES
 #define RT_SM_MIN_WAVES 4
 #endif
-#ifndef RT_SM_SPECULATIVE
-#define RT_SM_SPECULATIVE 0
-#endif
-#ifndef RT_SM_LEAF_THRESHOLD
-#define RT_SM_LEAF_THRESHOLD 24
-#endif
-#define REF_NONE RT_DEV_REF_NONE
 #ifndef RT_SM_PARK_THRESHOLD
 #define RT_SM_PARK_THRESHOLD 8
 #endif
@@ -264,9 +257,9 @@ enum : uint32_t { ST_NEW_SAMPLE = 0, ST_CLOSEST_DONE = 1, ST_SHADOW_DONE = 2, ST
 
 template <bool COUNT>
 __global__ __launch_bounds__(WAVE, RT_SM_MIN_WAVES) void k_render_extended_sm(DevScene sc, DevFrame fr, DevTargets tg) {
-    extern __shared__ uint32_t s_stack[]; // DevScene::stack_entries * 64 words
+    extern __shared__ uint2 s_stack[]; // DevScene::stack_entries * 64 64-bit entries
     const PixelCoord px = block_pixel(fr);
-    uint32_t* __restrict__ stack = s_stack + threadIdx.x;
+    uint2* __restrict__ stack = s_stack + threadIdx.x;
     const uint4* __restrict__ nodes = reinterpret_cast<const uint4*>(sc.nodes);
     Counts cnt = {0u, 0u};
     SegCounts seg = {0u, 0u, 0u};
@@ -288,10 +281,9 @@ __global__ __launch_bounds__(WAVE, RT_SM_MIN_WAVES) void k_render_extended_sm(De
     hit.t = RT_F32_MAX;
     hit.prim = RT_PRIM_MISS;
     hit.slot = 0;
-    uint32_t cur = REF_NONE;
-#if RT_SM_SPECULATIVE
-    uint32_t pleaf = REF_NONE;
-#endif
+    uint32_t g_base = 0, g_bits = 0; // inner children still to visit: (child_base, hits | imask << 8)
+    uint32_t t_base = 0, t_bits = 0; // leaves of the last visited node still to test: (tri_base, hits | lmask << 8)
+    uint32_t oct = 0;
     int sp = 0;
     bool anyhit = false;
 
@@ -304,13 +296,13 @@ __global__ __launch_bounds__(WAVE, RT_SM_MIN_WAVES) void k_render_extended_sm(De
         hit.prim = RT_PRIM_MISS;
         hit.slot = 0;
         anyhit = any;
+        oct = ray_octant(fray);
         test_spheres(sc, so, sd, hit);
         sp = 0;
-        cur = sc.root_ref;
-#if RT_SM_SPECULATIVE
-        pleaf = REF_NONE;
-#endif
-        const bool finished = sc.n_tris == 0 || (any && hit.prim != RT_PRIM_MISS);
+        g_base = 0;
+        g_bits = 1u | (1u << 8); // the root as the only child of a group
+        t_bits = 0;
+        const bool finished = sc.n_nodes == 0 || (any && hit.prim != RT_PRIM_MISS);
         state = finished ? (any ? ST_SHADOW_DONE : ST_CLOSEST_DONE) : ST_TRAVERSING;
     };
 
@@ -485,67 +477,20 @@ __global__ __launch_bounds__(WAVE, RT_SM_MIN_WAVES) void k_render_extended_sm(De
             continue;
         }
         // =========================== traversal phase ===========================
-#if RT_SM_SPECULATIVE
-        // Speculative descent with one postponed leaf per lane: a lane that reaches a leaf parks the leaf
-        // reference in `pleaf` and keeps walking (pops its next subtree) instead of waiting for the other lanes
-        // to reach theirs; the triangle tests run for many lanes at once when RT_SM_LEAF_THRESHOLD lanes hold a
-        // postponed leaf or no lane can take a node step.  Closest hit (and "any hit" existence) do not depend
-        // on the order in which leaves are tested - ties go to the lower triangle index - so this is
-        // result-neutral; its only cost is that culling sees the closest hit a little later.
-        for (;;) {
-            const bool trav = state == ST_TRAVERSING;
-            if (trav && (cur & RT_DEV_LEAF_FLAG) && cur != REF_NONE && pleaf == REF_NONE) {
-                pleaf = cur;
-                if (sp > 0) {
-                    sp--;
-                    cur = stack[sp * WAVE];
-                } else {
-                    cur = REF_NONE;
-                }
-            }
-            const bool can_node = trav && !(cur & RT_DEV_LEAF_FLAG);
-            const bool has_leaf = trav && pleaf != REF_NONE;
-            const unsigned long long m_node = __ballot(can_node);
-            const unsigned long long m_leaf = __ballot(has_leaf);
-            if (m_node != 0ull && __popcll(m_leaf) < RT_SM_LEAF_THRESHOLD) {
-                if (COUNT) {
-                    dg_ni++;
-                    dg_nl += __popcll(m_node);
-                }
-                if (can_node) {
-                    if (!visit_node4<COUNT>(nodes, fray, hit.t, stack, sp, cur, cnt)) cur = REF_NONE;
-                }
-            } else if (m_leaf != 0ull) {
-                if (COUNT) {
-                    dg_li++;
-                    dg_ll += __popcll(m_leaf);
-                }
-                if (has_leaf) {
-                    const uint32_t start = pleaf & RT_DEV_LEAF_START_MASK;
-                    pleaf = REF_NONE;
-                    uint32_t n_tri = 1;
-                    for (uint32_t i = 0; i < n_tri; i++) {
-                        if (COUNT) cnt.tris++;
-                        const uint32_t lc = test_triangle(sc.tris, start + i, o, d, hit);
-                        if (i == 0) n_tri = lc;
-                        if (anyhit && hit.prim != RT_PRIM_MISS) break;
-                    }
-                    if (anyhit && hit.prim != RT_PRIM_MISS) state = ST_SHADOW_DONE;
-                }
-            }
-            if (state == ST_TRAVERSING && cur == REF_NONE && pleaf == REF_NONE) state = anyhit ? ST_SHADOW_DONE : ST_CLOSEST_DONE;
-            const unsigned long long still = __ballot(state == ST_TRAVERSING);
-            const unsigned long long parked = __ballot(state != ST_TRAVERSING && state != ST_DONE);
-            if (still == 0ull || __popcll(parked) >= RT_SM_PARK_THRESHOLD) break;
-        }
-#else
-        // while-while: all lanes that stand on an inner node step until none does, then the lanes that reached
-        // a leaf test its triangles.  (A speculative variant that postpones one leaf per lane and keeps
-        // descending raised lane utilisation of the node steps from 26 % to 48 % but was not faster: the
-        // kernel is bound by vector-memory instructions per segment, not by idle lanes — DESIGN.md §4.)
+        // while-while on groups: every lane that has an inner child to visit (and no leaves waiting) steps until none has,
+        // then the lanes whose last visit entered leaves test them.  (A speculative variant that postponed one leaf per lane
+        // and kept descending raised lane utilisation of the node steps from 26 % to 48 % in round 1 but was not faster here;
+        // the queue pipeline's persistent kernels do postpone, wavefront.hip.)
         for (;;) {
             for (;;) {
-                const bool want = state == ST_TRAVERSING && !(cur & RT_DEV_LEAF_FLAG);
+                const bool trav = state == ST_TRAVERSING;
+                if (trav && (t_bits & 0xFFu) == 0u && (g_bits & 0xFFu) == 0u && sp > 0) {
+                    sp--;
+                    const uint2 e = stack[sp * WAVE];
+                    g_base = e.x;
+                    g_bits = e.y;
+                }
+                const bool want = trav && (t_bits & 0xFFu) == 0u && (g_bits & 0xFFu) != 0u;
                 const unsigned long long wmask = __ballot(want);
                 if (wmask == 0ull) break;
                 if (COUNT) {
@@ -553,45 +498,53 @@ __global__ __launch_bounds__(WAVE, RT_SM_MIN_WAVES) void k_render_extended_sm(De
                     dg_nl += __popcll(wmask);
                 }
                 if (want) {
-                    if (!visit_node4<COUNT>(nodes, fray, hit.t, stack, sp, cur, cnt))
-                        state = anyhit ? ST_SHADOW_DONE : ST_CLOSEST_DONE;
+                    const uint32_t i = first_slot(g_bits, oct);
+                    g_bits ^= 1u << i;
+                    const uint32_t node = g_base + (uint32_t)__popc(__builtin_amdgcn_ubfe(g_bits, 8u, i));
+                    if (g_bits & 0xFFu) {
+                        stack[sp * WAVE] = make_uint2(g_base, g_bits);
+                        sp++;
+                    }
+                    uint32_t cb, tb, im, lm;
+                    const uint32_t hm = visit_node8<COUNT>(nodes, node, fray, hit.t, cnt, cb, tb, im, lm);
+                    g_base = cb;
+                    g_bits = (hm & im) | (im << 8);
+                    t_base = tb;
+                    t_bits = (hm & lm) | (lm << 8);
                 }
             }
             if (COUNT) {
-                unsigned long long lm = __ballot(state == ST_TRAVERSING);
-                if (lm) {
+                unsigned long long lm_ = __ballot(state == ST_TRAVERSING && (t_bits & 0xFFu) != 0u);
+                if (lm_) {
                     dg_li++;
-                    dg_ll += __popcll(lm);
+                    dg_ll += __popcll(lm_);
                 }
             }
-            if (state == ST_TRAVERSING) { // cur is a leaf reference here
+            if (state == ST_TRAVERSING) {
                 // `anyhit` differs between lanes, so one loop serves both kinds (any-hit lanes leave it at their first hit)
-                const uint32_t start = cur & RT_DEV_LEAF_START_MASK;
                 bool stop = false;
-                uint32_t n_tri = 1;
-                for (uint32_t i = 0; i < n_tri; i++) {
-                    if (COUNT) cnt.tris++;
-                    const uint32_t lc = test_triangle(sc.tris, start + i, o, d, hit);
-                    if (i == 0) n_tri = lc;
-                    if (anyhit && hit.prim != RT_PRIM_MISS) {
-                        stop = true;
-                        break;
+                while ((t_bits & 0xFFu) != 0u && !stop) {
+                    const uint32_t sl = first_slot(t_bits, oct);
+                    t_bits ^= 1u << sl;
+                    const uint32_t start = t_base + RT_DEV_LEAF_STRIDE * (uint32_t)__popc(__builtin_amdgcn_ubfe(t_bits, 8u, sl));
+                    uint32_t n_tri = 1;
+                    for (uint32_t i = 0; i < n_tri; i++) {
+                        if (COUNT) cnt.tris++;
+                        const uint32_t lc = test_triangle(sc.tris, start + i, o, d, hit);
+                        if (i == 0) n_tri = lc;
+                        if (anyhit && hit.prim != RT_PRIM_MISS) {
+                            stop = true;
+                            break;
+                        }
                     }
                 }
-                if (stop) {
-                    state = ST_SHADOW_DONE;
-                } else if (sp > 0) {
-                    sp--;
-                    cur = stack[sp * WAVE];
-                } else {
-                    state = anyhit ? ST_SHADOW_DONE : ST_CLOSEST_DONE;
-                }
+                if (stop) state = ST_SHADOW_DONE;
+                else if ((g_bits & 0xFFu) == 0u && sp == 0) state = anyhit ? ST_SHADOW_DONE : ST_CLOSEST_DONE;
             }
             const unsigned long long still = __ballot(state == ST_TRAVERSING);
             const unsigned long long parked = __ballot(state != ST_TRAVERSING && state != ST_DONE);
             if (still == 0ull || __popcll(parked) >= RT_SM_PARK_THRESHOLD) break;
         }
-#endif
         if (COUNT) dg_cv += __builtin_readcyclecounter() - t_begin;
     }
     unsigned long long c0 = wave_sum(seg.camera), c1 = wave_sum(seg.continuation), c2 = wave_sum(seg.shadow);
@@ -620,7 +573,7 @@ __global__ __launch_bounds__(WAVE, RT_SM_MIN_WAVES) void k_render_extended_sm(De
 
 namespace rt {
 
-static size_t lds_bytes(const DevScene& sc) { return (size_t)(sc.stack_entries + 3u) * WAVE * sizeof(uint32_t); } // +3: visit_node4 stores three words unconditionally
+static size_t lds_bytes(const DevScene& sc) { return (size_t)(sc.stack_entries ? sc.stack_entries : 1u) * WAVE * sizeof(uint2); }
 
 __global__ __launch_bounds__(256) void k_combine_rgba8(const uint32_t* __restrict__ red, const uint32_t* __restrict__ green, const uint32_t* __restrict__ blue,
                                                         uint32_t* __restrict__ out, size_t n) {

@@ -30,13 +30,11 @@ struct DeviceState {
     int device = -1;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    DevNode4* nodes = nullptr;
+    DevNode8* nodes = nullptr;
     DevTri* tris = nullptr;
     DevSphere* spheres = nullptr;
     DevLight* lights = nullptr;
     DevMaterial* materials = nullptr;
-    DevNode8* nodes8 = nullptr; // 8-wide experiment (RT_BVH8=1)
-    DevTri* tris8 = nullptr;
     float* rgba32f = nullptr;
     uint8_t* chan[3] = {nullptr, nullptr, nullptr};
     uint32_t* prim_id = nullptr;
@@ -99,9 +97,8 @@ double now_ms() {
 void free_scene(DeviceState& d) {
     (void)hipSetDevice(d.device);
     (void)hipFree(d.nodes); (void)hipFree(d.tris); (void)hipFree(d.spheres); (void)hipFree(d.lights); (void)hipFree(d.materials);
-    (void)hipFree(d.nodes8); (void)hipFree(d.tris8);
     d.nodes = nullptr; d.tris = nullptr; d.spheres = nullptr; d.lights = nullptr; d.materials = nullptr;
-    d.nodes8 = nullptr; d.tris8 = nullptr;
+
 }
 void free_targets(DeviceState& d) {
     (void)hipSetDevice(d.device);
@@ -190,8 +187,6 @@ DevScene scene_for(const rt_ctx* ctx, const DeviceState& d) {
     s.spheres = d.spheres;
     s.lights = d.lights;
     s.materials = d.materials;
-    s.nodes8 = d.nodes8;
-    s.tris8 = d.tris8;
     return s;
 }
 
@@ -228,8 +223,6 @@ int upload_common(rt_ctx* ctx, const rt_sphere* spheres, uint32_t n_spheres, con
     rt::BvhBuildOptions opt;
     if (const char* e = std::getenv("RT_BVH_COST_TRAVERSE")) opt.cost_traverse = (float)std::atof(e); // tuning knobs (development)
     if (const char* e = std::getenv("RT_BVH_MAX_LEAF")) opt.max_leaf = (uint32_t)std::atoi(e);
-    opt.wide8 = true; // the wavefront pipeline's persistent traversal kernels walk the 8-wide tree (RT_BVH8=0: the 4-wide one, for A/B)
-    if (const char* e = std::getenv("RT_BVH8")) opt.wide8 = std::atoi(e) != 0;
     if (const char* e = std::getenv("RT_BVH8_COST_TRAVERSE")) opt.cost_traverse8 = (float)std::atof(e);
     double t0 = now_ms();
     rt::build_bvh(bt.data(), bt.size(), opt, bvh);
@@ -293,8 +286,6 @@ int upload_common(rt_ctx* ctx, const rt_sphere* spheres, uint32_t n_spheres, con
         if ((rc = upload_array(ctx, &d.spheres, ds)) != RT_OK) return rc;
         if ((rc = upload_array(ctx, &d.lights, dl)) != RT_OK) return rc;
         if ((rc = upload_array(ctx, &d.materials, dm)) != RT_OK) return rc;
-        if ((rc = upload_array(ctx, &d.nodes8, bvh.nodes8)) != RT_OK) return rc;
-        if ((rc = upload_array(ctx, &d.tris8, bvh.tris8)) != RT_OK) return rc;
         // the copies went through the null stream and d.stream is non-blocking: make the order explicit
         HIPCHK(ctx, hipDeviceSynchronize());
         return RT_OK;
@@ -315,14 +306,11 @@ int upload_common(rt_ctx* ctx, const rt_sphere* spheres, uint32_t n_spheres, con
     sc.n_spheres = n_spheres;
     sc.n_lights = n_lights;
     sc.n_materials = n_materials;
-    sc.root_ref = bvh.root_ref;
-    sc.stack_entries = 3u * bvh.depth + 1u; // a visit pushes at most 3 references
-    sc.n_nodes8 = (uint32_t)bvh.nodes8.size();
-    sc.stack_entries8 = 2u * bvh.depth8 + 2u; // a visit parks at most two groups
+    sc.stack_entries = 2u * bvh.depth + 2u; // a visit parks at most two groups
     ctx->stats = rt_stats{};
-    ctx->stats.node_bytes = sizeof(DevNode4);
+    ctx->stats.node_bytes = sizeof(DevNode8);
     ctx->stats.tri_bytes = sizeof(DevTri);
-    ctx->stats.scene_bytes = bvh.nodes.size() * sizeof(DevNode4) + bvh.tris.size() * sizeof(DevTri) + ds.size() * sizeof(DevSphere) +
+    ctx->stats.scene_bytes = bvh.nodes.size() * sizeof(DevNode8) + bvh.tris.size() * sizeof(DevTri) + ds.size() * sizeof(DevSphere) +
                              dl.size() * sizeof(DevLight) + dm.size() * sizeof(DevMaterial);
     ctx->stats.bvh_nodes = sc.n_nodes;
     ctx->stats.bvh_depth = bvh.depth;
@@ -337,12 +325,10 @@ int upload_common(rt_ctx* ctx, const rt_sphere* spheres, uint32_t n_spheres, con
 // Path-state arrays and queues of the wavefront pipeline, sized for `batch` samples per owned pixel block.
 int ensure_wavefront(rt_ctx* ctx, DeviceState& d, uint32_t n_blocks, uint32_t batch, uint32_t n_lights) {
     const uint32_t capacity = n_blocks * batch * 64u;
-    const bool use8 = ctx->scene_counts.n_nodes8 != 0;
-    // overflow entries per lane beyond the LDS part of the stack, in 8-byte units (the 8-wide walk stores 64-bit groups, 8 in LDS)
-    const uint32_t ovf4 = ctx->scene_counts.stack_entries + 3u > RT_WF_LDS_STACK ? ctx->scene_counts.stack_entries + 3u - RT_WF_LDS_STACK : 1u;
-    const uint32_t ovf_entries = use8 ? std::max(ovf4, ctx->scene_counts.stack_entries8 + 2u) : ovf4;
+    // overflow entries (64-bit) per lane beyond the LDS part of the stack
+    const uint32_t ovf_entries = ctx->scene_counts.stack_entries + 2u > RT_WF8_LDS_STACK ? ctx->scene_counts.stack_entries + 2u - RT_WF8_LDS_STACK : 1u;
     if (d.wf.capacity >= capacity && d.wf.n_blocks == n_blocks && d.wf.batch == batch && d.wf_lights >= n_lights && d.wf.counters &&
-        d.wf.ovf_entries >= ovf_entries && d.wf.use8 == (use8 ? 1u : 0u))
+        d.wf.ovf_entries >= ovf_entries)
         return RT_OK;
     free_wavefront(d);
     HIPCHK(ctx, hipSetDevice(d.device));
@@ -376,7 +362,6 @@ int ensure_wavefront(rt_ctx* ctx, DeviceState& d, uint32_t n_blocks, uint32_t ba
     HIPCHK(ctx, alloc((void**)&w.totals, 16 * sizeof(unsigned long long)));
     HIPCHK(ctx, alloc((void**)&w.accum, (size_t)std::max(1u, n_blocks) * 64 * 16));
     HIPCHK(ctx, alloc((void**)&w.stack_ovf, (size_t)rt::wf_persistent_waves() * ovf_entries * 64 * 8));
-    w.use8 = use8 ? 1u : 0u;
     w.ovf_entries = ovf_entries;
     w.n_blocks = n_blocks;
     w.batch = batch;
@@ -571,8 +556,6 @@ int run_frame(rt_ctx* ctx, DevFrame fr, bool counters, uint32_t world, uint32_t 
     st.kernel_ms = kernel_ms;
     st.wall_ms = now_ms() - w0;
     st.flags = fallback ? RT_STAT_MEGAKERNEL_FALLBACK : 0u;
-    // bytes of one node record of the tree the last render walked: the queue pipeline walks the 8-wide tree
-    st.node_bytes = (extended && ctx->devs[0].used_wavefront && ctx->devs[0].wf.use8) ? sizeof(DevNode8) : sizeof(DevNode4);
     return RT_OK;
 }
 

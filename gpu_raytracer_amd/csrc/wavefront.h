@@ -48,16 +48,15 @@ struct WfBuffers {
     float4* accum;       // per owned pixel slot: running sum over samples (in sample order)
     uint32_t q_ext_cap;  // slots allocated for each extension queue / the shadow queue: a window reservation that would
     uint32_t q_shadow_cap; // end beyond it raises totals[WF_TOTAL_ERROR] instead of writing (window_reserve)
-    uint32_t* stack_ovf; // global overflow part of the traversal stacks: [persistent wave][entry][lane]
+    uint32_t* stack_ovf; // global overflow part of the traversal stacks: [persistent wave][entry][lane], 64-bit entries
     uint32_t ovf_entries; // entries per lane in it
     uint32_t n_blocks;   // 8x8 pixel blocks owned by this device
     uint32_t batch;      // samples per pixel in flight
     uint32_t capacity;   // path slots
-    uint32_t use8;       // experiment: the traversal stages walk the 8-wide tree (DevScene::nodes8 / tris8)
 };
 
 #define WF_TOTAL_ERROR 15 /* totals[] slot: non-zero = a queue reservation did not fit; every later stage kernel of the frame returns at once */
-#define RT_WF_LDS_STACK 16 /* traversal stack entries kept in LDS by the persistent kernels; deeper ones overflow to HBM */
+#define RT_WF8_LDS_STACK 8 /* 64-bit traversal stack entries per lane kept in LDS by the persistent kernels; deeper ones overflow to HBM */
 #define RT_WF_MAX_LIGHTS 32u /* visibility is one bit per light in a 32-bit word */
 #define RT_WF_ID_MASK 0x07FFFFFFu
 

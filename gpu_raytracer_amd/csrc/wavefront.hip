@@ -178,187 +178,14 @@ __global__ __launch_bounds__(256) void k_wf_generate(DevFrame fr, rt::WfBuffers 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// persistent traversal kernel (closest hit for extension segments, any hit for shadow segments)
-// ---------------------------------------------------------------------------------------------------------
-template <bool COUNT, bool ANY>
-__global__ __launch_bounds__(WAVE, RT_WF_MIN_WAVES) void k_wf_trace(DevScene sc, rt::WfBuffers wb, const uint32_t* __restrict__ queue, uint32_t count_slot,
-                                                   uint32_t cursor_slot, uint32_t window_slot) {
-    extern __shared__ uint32_t s_stack[];
-    if (wb.totals[WF_TOTAL_ERROR] != 0ull) return; // an earlier stage overran a queue: its contents are not to be trusted
-    const uint32_t lane = threadIdx.x;
-    uint32_t* __restrict__ stack = s_stack + lane;
-    uint32_t* __restrict__ ovf = wb.stack_ovf + (size_t)blockIdx.x * wb.ovf_entries * WAVE + lane;
-    const uint4* __restrict__ nodes = reinterpret_cast<const uint4*>(sc.nodes);
-    const uint32_t count = wb.counters[count_slot];
-    const uint32_t window_mask = max(wb.counters[window_slot], 1u) - 1u; // the producers' window size is a power of two
-    uint32_t* cursor = &wb.counters[cursor_slot];
-    uint32_t cursor_seen = 0; // the furthest queue position this wave knows to be handed out (wave-uniform)
-    Counts cnt = {0u, 0u};
-    int sp_max = 0;
-    uint32_t sp_gt16 = 0, sp_gt24 = 0;
-    uint32_t d_node_steps = 0, d_leaf_steps = 0, d_leaf_lanes = 0, d_leaf_trips = 0, d_refills = 0; // wave-uniform diagnostics (COUNT)
-
-    bool active = false, exhausted = false;
-    uint32_t chunk_next = 0, chunk_end = 0; // wave-uniform
-    uint32_t id = 0, li = 0;
-    V3 o = v3(0.0f, 0.0f, 0.0f), d = o;
-    FilterRay fray;
-    fray.o = o;
-    fray.inv = o;
-    Hit hit;
-    hit.t = RT_F32_MAX;
-    hit.prim = RT_PRIM_MISS;
-    hit.slot = 0;
-    uint32_t cur = WF_REF_NONE, pleaf = WF_REF_NONE;
-    int sp = 0;
-
-    for (;;) {
-        // ---- refill: idle lanes take the next queue entries.  The wave owns a private chunk [chunk_next, chunk_end)
-        // of the queue and only touches the global cursor when it runs dry: a single counter sustains ~90 M
-        // atomics/s, far less than thousands of waves refilling 16 lanes at a time would ask of it.
-        const unsigned long long idle = __ballot(!active);
-        if (!exhausted && (__popcll(idle) >= RT_WF_REFILL || idle == ~0ull)) {
-            if (chunk_next >= chunk_end) {
-                // guided self-scheduling: claim 1/(2 x waves) of what is left, at least RT_WF_CHUNK entries.  Fixed
-                // 256-entry chunks cost one atomic per 256 entries on ONE address (650 k per large launch, ~7 ms
-                // of its 22 ms at ~90 M atomics/s); this needs a few dozen per wave and still ends balanced.
-                const uint32_t left = count > cursor_seen ? count - cursor_seen : 0u;
-                const uint32_t want = min(max(left / (2u * gridDim.x), (uint32_t)RT_WF_CHUNK), (uint32_t)RT_WF_CHUNK_MAX) & ~63u;
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(cursor, want);
-                base = __shfl(base, 0, WAVE);
-                cursor_seen = base + want;
-                chunk_next = base;
-                chunk_end = min(base + want, count);
-                if (base >= count) exhausted = true;
-            }
-            if (!exhausted) {
-                if (COUNT) d_refills++;
-                const uint32_t n_fetch = (uint32_t)__popcll(idle);
-                const uint32_t idx = chunk_next + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-                const uint32_t last = min(chunk_next + n_fetch, chunk_end) - 1u; // last position fetched now
-                chunk_next += n_fetch;
-                uint32_t e = WF_SENTINEL;
-                if (!active && idx < chunk_end) e = queue[idx];
-                // sentinels are the tail of a producer window: if the last entry fetched is one, so is the rest of its window
-                if (__ballot(!active && idx == last && e == WF_SENTINEL) != 0ull) chunk_next = max(chunk_next, (last + window_mask + 1u) & ~window_mask);
-                if (e != WF_SENTINEL) { // padding entries of the producers' windows carry no work
-                    if (ANY) {
-                        id = e & RT_WF_ID_MASK;
-                        li = e >> 27;
-                        const V3 point = f4v(wb.vtx_p[id]), normal = f4v(wb.vtx_n[id]);
-                        float dist;
-                        shadow_segment(sc.lights[li], point, d, dist);
-                        o = point + normal * EXT_EPS;
-                        hit.t = dist;
-                    } else {
-                        id = e;
-                        o = f4v(wb.ray_o[id]);
-                        d = f4v(wb.ray_d[id]);
-                        hit.t = RT_F32_MAX;
-                    }
-                    hit.prim = RT_PRIM_MISS;
-                    hit.slot = 0;
-                    fray = make_filter_ray(o, d);
-                    test_spheres(sc, o, d, hit);
-                    sp = 0;
-                    cur = sc.n_tris ? sc.root_ref : WF_REF_NONE;
-                    pleaf = WF_REF_NONE;
-                    active = true;
-                    if (ANY && hit.prim != RT_PRIM_MISS) cur = WF_REF_NONE; // occluded by a sphere already
-                }
-            }
-        }
-        if (__ballot(active) == 0ull) {
-            if (exhausted) break;
-            continue;
-        }
-        // ---- traversal steps until enough lanes have finished ----
-        for (;;) {
-            if (active && (cur & RT_DEV_LEAF_FLAG) && cur != WF_REF_NONE && pleaf == WF_REF_NONE) {
-                pleaf = cur; // postpone the leaf, keep descending
-                if (sp > 0) {
-                    sp--;
-                    cur = stack_pop<RT_WF_LDS_STACK>(stack, ovf, sp);
-                } else {
-                    cur = WF_REF_NONE;
-                }
-            }
-            const bool can_node = active && !(cur & RT_DEV_LEAF_FLAG);
-            const bool has_leaf = active && pleaf != WF_REF_NONE;
-            const unsigned long long m_node = __ballot(can_node), m_leaf = __ballot(has_leaf);
-#if RT_WF_LEAF_POLICY == 1
-            const unsigned long long m_gate = __ballot(has_leaf && !can_node); // lanes that cannot step before their leaf is tested
-#else
-            const unsigned long long m_gate = m_leaf;
-#endif
-            if (m_node != 0ull && __popcll(m_gate) < RT_WF_LEAF_THRESHOLD) {
-                if (COUNT) d_node_steps++;
-                if (can_node) {
-                    if (!visit_node4<COUNT, RT_WF_LDS_STACK>(nodes, fray, hit.t, stack, sp, cur, cnt, ovf)) cur = WF_REF_NONE;
-                    if (COUNT) {
-                        sp_max = max(sp_max, sp);
-                        sp_gt16 += sp > 16 ? 1u : 0u;
-                        sp_gt24 += sp > 24 ? 1u : 0u;
-                    }
-                }
-            } else if (m_leaf != 0ull) {
-                uint32_t trips = 0;
-                if (has_leaf) {
-                    const uint32_t before = cnt.tris;
-                    const uint32_t leaf = pleaf;
-                    pleaf = WF_REF_NONE;
-                    if (test_leaf<COUNT, ANY>(sc.tris, leaf, o, d, hit, cnt)) cur = WF_REF_NONE; // occluded: nothing more to do
-                    trips = cnt.tris - before;
-                }
-                if (COUNT) {
-                    d_leaf_steps++;
-                    d_leaf_lanes += (uint32_t)__popcll(m_leaf);
-                    for (int off = 32; off > 0; off >>= 1) trips = max(trips, (uint32_t)__shfl_xor((int)trips, off, WAVE));
-                    d_leaf_trips += trips;
-                }
-            }
-            if (active && cur == WF_REF_NONE && pleaf == WF_REF_NONE) { // segment finished
-                if (ANY) {
-                    if (hit.prim == RT_PRIM_MISS) atomicOr(reinterpret_cast<uint32_t*>(&wb.vtx_n[id]) + 3, 1u << li); // visibility bits live in vtx_n.w
-                } else {
-                    // the hit POINT (Ray::at, ray.rs:56-58: o + d * t) and what was hit: k_wf_shade then needs neither the
-                    // ray nor t (32 bytes less to read per vertex)
-                    const V3 hp = o + d * hit.t;
-                    const uint32_t code = hit.prim == RT_PRIM_MISS ? RT_PRIM_MISS : ((hit.prim & RT_PRIM_SPHERE_FLAG) ? hit.prim : hit.slot);
-                    wb.hit[id] = make_uint4(__float_as_uint(hp.x), __float_as_uint(hp.y), __float_as_uint(hp.z), code);
-                }
-                active = false;
-            }
-            const unsigned long long still = __ballot(active);
-            if (still == 0ull) break;
-            if (!exhausted && __popcll(~still) >= RT_WF_REFILL) break;
-        }
-    }
-    if (COUNT) {
-        unsigned long long n0 = wave_sum(cnt.nodes), n1 = wave_sum(cnt.tris);
-        unsigned long long g16 = wave_sum(sp_gt16), g24 = wave_sum(sp_gt24);
-        for (int off = 32; off > 0; off >>= 1) sp_max = max(sp_max, __shfl_down(sp_max, off, WAVE));
-        if (lane == 0) {
-            atomicAdd(&wb.totals[3], n0);
-            atomicAdd(&wb.totals[4], n1);
-            atomicMax(&wb.totals[5], (unsigned long long)sp_max);
-            atomicAdd(&wb.totals[6], g16);
-            atomicAdd(&wb.totals[7], g24);
-            atomicAdd(&wb.totals[8], (unsigned long long)d_node_steps);
-            atomicAdd(&wb.totals[9], (unsigned long long)d_leaf_steps);
-            atomicAdd(&wb.totals[10], (unsigned long long)d_leaf_lanes);
-            atomicAdd(&wb.totals[11], (unsigned long long)d_leaf_trips);
-            atomicAdd(&wb.totals[12], (unsigned long long)d_refills);
-        }
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------------------
-// 8-wide variant of the persistent traversal kernel (experiment, DevNode8).  What is left of a visited node is a group:
-// (base, hit mask | kind mask << 8) - G for its inner children, T for its leaves - so a visit pushes at most two 64-bit
-// entries, and children are taken from a group in increasing (slot XOR ray octant) through a 2 KB table in LDS.
+// persistent traversal kernel (closest hit for extension segments, any hit for shadow segments) on the 8-wide tree.
+// A wave owns a private chunk of 256 queue entries; when >= RT_WF_REFILL lanes are idle they take the next entries
+// (__ballot + prefix count of the idle mask, no atomic until the chunk is used up).  Traversal is speculative with one
+// postponed leaf GROUP per lane: what is left of a visited node is a group (base, hit mask | kind mask << 8) - G for its
+// inner children, T for its leaves; a lane keeps descending through G while T waits, triangle tests run when
+// RT_WF8_LEAF_THRESHOLD lanes hold a T (result-neutral: ties resolve by triangle index, not by visiting order).  A visit
+// parks at most two 64-bit entries; children are taken from a group in increasing (slot XOR ray octant) through a 2 KB
+// table in LDS (device_common.h first_slot computes the same function arithmetically for the other kernels).
 // ---------------------------------------------------------------------------------------------------------
 #ifndef RT_WF8_LDS_STACK
 #define RT_WF8_LDS_STACK 8 /* 64-bit entries per lane kept in LDS; deeper ones go to the HBM overflow area */
@@ -373,7 +200,7 @@ __global__ __launch_bounds__(WAVE, RT_WF_MIN_WAVES) void k_wf_trace(DevScene sc,
 #define WF8_NONE 0xFFFFFFFFu
 
 template <bool COUNT, bool ANY>
-__global__ __launch_bounds__(WAVE, RT_WF8_MIN_WAVES) void k_wf_trace8(DevScene sc, rt::WfBuffers wb, const uint32_t* __restrict__ queue, uint32_t count_slot,
+__global__ __launch_bounds__(WAVE, RT_WF8_MIN_WAVES) void k_wf_trace(DevScene sc, rt::WfBuffers wb, const uint32_t* __restrict__ queue, uint32_t count_slot,
                                                     uint32_t cursor_slot, uint32_t window_slot) {
     extern __shared__ uint32_t s_mem8[];
     if (wb.totals[WF_TOTAL_ERROR] != 0ull) return;
@@ -389,7 +216,7 @@ __global__ __launch_bounds__(WAVE, RT_WF8_MIN_WAVES) void k_wf_trace8(DevScene s
     }
     __syncthreads();
     uint2* __restrict__ ovf = reinterpret_cast<uint2*>(wb.stack_ovf) + (size_t)blockIdx.x * wb.ovf_entries * WAVE + lane;
-    const uint4* __restrict__ nodes = reinterpret_cast<const uint4*>(sc.nodes8);
+    const uint4* __restrict__ nodes = reinterpret_cast<const uint4*>(sc.nodes);
     const uint32_t count = wb.counters[count_slot];
     const uint32_t window_mask = max(wb.counters[window_slot], 1u) - 1u;
     uint32_t* cursor = &wb.counters[cursor_slot];
@@ -457,13 +284,9 @@ __global__ __launch_bounds__(WAVE, RT_WF8_MIN_WAVES) void k_wf_trace8(DevScene s
                     sp = 0;
                     cur = WF8_NONE;
                     t_bits = 0;
-                    // the root as the only child of a group: node 0 (an inner root always exists when the scene has more than one leaf)
+                    // the root as the only child of a group: node 0 (the builder gives every non-empty scene an inner root)
                     g_base = 0;
-                    g_bits = sc.n_nodes8 ? (1u | (1u << 8)) : 0u;
-                    if (sc.n_nodes8 == 0 && sc.n_tris) { // the whole scene is one leaf at record 0
-                        t_base = 0;
-                        t_bits = 1u | (1u << 8);
-                    }
+                    g_bits = sc.n_nodes ? (1u | (1u << 8)) : 0u;
                     active = true;
                     if (ANY && hit.prim != RT_PRIM_MISS) g_bits = t_bits = 0; // occluded by a sphere already
                 }
@@ -534,7 +357,7 @@ __global__ __launch_bounds__(WAVE, RT_WF8_MIN_WAVES) void k_wf_trace8(DevScene s
                     const uint32_t i = lut[oct + (t_bits & 0xFFu)];
                     t_bits ^= 1u << i;
                     const uint32_t first = t_base + RT_DEV_LEAF_STRIDE * (uint32_t)__popc(__builtin_amdgcn_ubfe(t_bits, 8u, i));
-                    if (test_leaf<COUNT, ANY>(sc.tris8, RT_DEV_LEAF_FLAG | first, o, d, hit, cnt)) { // occluded: nothing more to do
+                    if (test_leaf<COUNT, ANY>(sc.tris, RT_DEV_LEAF_FLAG | first, o, d, hit, cnt)) { // occluded: nothing more to do
                         cur = WF8_NONE;
                         g_bits = t_bits = 0u;
                         sp = 0;
@@ -614,7 +437,6 @@ __device__ __forceinline__ void wf_end_path(const rt::WfBuffers& wb, uint32_t id
 
 __global__ __launch_bounds__(256, RT_WF_SHADE_WAVES) void k_wf_shade(DevScene sc, DevFrame fr, rt::WfBuffers wb, const uint32_t* __restrict__ queue) {
     __shared__ DevLight s_lights[RT_WF_MAX_LIGHTS];
-    if (wb.use8) sc.tris = sc.tris8; // hit records name triangle slots of the array the traversal walked
     if (wb.totals[WF_TOTAL_ERROR] != 0ull) return;
     stage_lights(s_lights, sc);
     const uint32_t count = wb.counters[rt::WF_EXT_COUNT];
@@ -933,19 +755,11 @@ hipError_t wf_generate(const DevScene&, const DevFrame& fr, const WfBuffers& wb,
 
 template <bool COUNT, bool ANY>
 static void launch_trace(const DevScene& sc, const WfBuffers& wb, const uint32_t* q, uint32_t count_slot, uint32_t cursor_slot, uint32_t window_slot, hipStream_t s) {
-    const dim3 pgrid(wf_persistent_waves()), pblock(WAVE);
-    if (wb.use8) {
-        const size_t lds8 = (size_t)RT_WF8_LDS_STACK * WAVE * sizeof(uint2) + 2048;
-        hipLaunchKernelGGL((k_wf_trace8<COUNT, ANY>), pgrid, pblock, lds8, s, sc, wb, q, count_slot, cursor_slot, window_slot);
-    } else {
-        const size_t lds = (size_t)RT_WF_LDS_STACK * WAVE * sizeof(uint32_t);
-        hipLaunchKernelGGL((k_wf_trace<COUNT, ANY>), pgrid, pblock, lds, s, sc, wb, q, count_slot, cursor_slot, window_slot);
-    }
+    const size_t lds = (size_t)RT_WF8_LDS_STACK * WAVE * sizeof(uint2) + 2048;
+    hipLaunchKernelGGL((k_wf_trace<COUNT, ANY>), dim3(wf_persistent_waves()), dim3(WAVE), lds, s, sc, wb, q, count_slot, cursor_slot, window_slot);
 }
 
 hipError_t wf_bounce(const DevScene& sc, const DevFrame& fr, const WfBuffers& wb, uint32_t iteration, bool counters, hipStream_t s) {
-    const size_t lds = (size_t)RT_WF_LDS_STACK * WAVE * sizeof(uint32_t);
-    (void)lds;
     const dim3 sgrid(wf_shading_blocks()), sblock(256);
     uint32_t* cur_q = wb.q_ext[iteration & 1u];
     uint32_t* next_q = wb.q_ext[(iteration + 1u) & 1u];

@@ -1,10 +1,12 @@
-// Structural validator for the 4-wide quantised tree of gpu_raytracer_amd/csrc/bvh_builder.cpp (host code; built by
-// tests/test_device_bvh.py with AddressSanitizer + UBSan).  It decodes nodes exactly as visit_node4 does and checks
-// what the kernels rely on:
-//   * every child reference names a node / triangle inside the arrays - including the slots of ABSENT children,
-//     which a degenerate float evaluation may enter (they must decode to a real leaf);
+// Structural validator for the 8-wide quantised tree of gpu_raytracer_amd/csrc/bvh_builder.cpp (host code; built by
+// tests/test_device_bvh.py with AddressSanitizer + UBSan).  It decodes nodes exactly as visit_node8 and the group walk do
+// and checks what the kernels rely on:
+//   * node 0 is the root of every non-empty build; inner children are consecutive nodes in slot order
+//     (child_base + number of inner slots below), every leaf owns RT_DEV_LEAF_STRIDE records in slot order
+//     (tri_base + stride * number of leaf slots below); imask and lmask are disjoint; a slot that is in neither is
+//     EMPTY and its box inverted (the walk masks hits with imask | lmask, so a degenerate evaluation cannot follow it);
 //   * every input triangle with finite coordinates appears in exactly one leaf, leaves hold 1..4 triangles, the run
-//     length sits in the first record of the leaf and only there;
+//     length sits in the first record of the leaf and only there (padding records carry none);
 //   * every triangle lies inside the dequantised box of every ancestor's child slot (the boxes are conservative);
 //   * the reported depth bounds the real one and stays within the stack the kernels provide.
 // usage: check_bvh <n_triangles> <seed> <kind>   kind: 0 soup, 1 coplanar grid, 2 coincident points, 3 collinear chain,
@@ -40,14 +42,14 @@ struct Ctx {
     size_t leaves = 0;
 };
 
-static void check_leaf(Ctx& c, uint32_t ref, const double lo[3], const double hi[3], bool have_box) {
-    const uint32_t start = ref & RT_DEV_LEAF_START_MASK;
+static void check_leaf(Ctx& c, uint32_t start, const double lo[3], const double hi[3], bool have_box) {
     CHECK(start < c.b->tris.size(), "leaf start %u out of %zu", start, c.b->tris.size());
     if (start >= c.b->tris.size()) return;
     const uint32_t count = c.b->tris[start].leaf_count;
-    CHECK(count >= 1 && count <= RT_DEV_MAX_LEAF_TRIS, "leaf at %u has count %u", start, count);
-    CHECK((size_t)start + count <= c.b->tris.size(), "leaf at %u runs past the array", start);
-    if (count < 1 || (size_t)start + count > c.b->tris.size()) return;
+    CHECK(count >= 1 && count <= RT_DEV_LEAF_STRIDE, "leaf at %u has count %u", start, count);
+    CHECK((size_t)start + RT_DEV_LEAF_STRIDE <= c.b->tris.size(), "leaf at %u runs past the array", start);
+    if (count < 1 || count > RT_DEV_LEAF_STRIDE || (size_t)start + RT_DEV_LEAF_STRIDE > c.b->tris.size()) return;
+    for (uint32_t i = count; i < RT_DEV_LEAF_STRIDE; i++) CHECK(c.b->tris[start + i].leaf_count == 0, "padding record %u carries a count", start + i);
     c.leaves++;
     for (uint32_t i = 0; i < count; i++) {
         const DevTri& t = c.b->tris[start + i];
@@ -71,48 +73,43 @@ static void check_node(Ctx& c, uint32_t node, uint32_t depth, const double plo[3
     c.max_depth = depth > c.max_depth ? depth : c.max_depth;
     CHECK(depth <= RT_DEV_MAX_BVH_DEPTH, "depth %u beyond the bound", depth);
     if (depth > RT_DEV_MAX_BVH_DEPTH) return;
-    const DevNode4& n = c.b->nodes[node];
-    const uint32_t child_off = (n.ex_off >> 24) | ((n.base_off >> 16) & 0xFF00u);
-    const uint32_t base_inner = n.base_off & RT_DEV_NODE_BASE_MASK;
-    const uint32_t base_leaf = (n.tri_inf & RT_DEV_TRI_BASE_MASK) | RT_DEV_LEAF_FLAG;
-    const uint32_t n_inner = (n.tri_inf >> 27) & 7u;
-    CHECK(n_inner <= 4, "node %u: n_inner %u", node, n_inner);
+    const DevNode8& n = c.b->nodes[node];
+    const uint32_t imask = n.ex_imask >> 24, lmask = n.lmask & 0xFFu;
+    CHECK((imask & lmask) == 0, "node %u: slot both inner and leaf (imask %02x lmask %02x)", node, imask, lmask);
+    CHECK((n.lmask >> 8) == 0, "node %u: lmask has high bits", node);
     double scale[3];
     for (int a = 0; a < 3; a++) {
-        const int k = (int)(int8_t)((n.ex_off >> (8 * a)) & 0xFFu);
+        const int k = (int)(int8_t)((n.ex_imask >> (8 * a)) & 0xFFu);
         CHECK(k >= -126 && k <= 127, "node %u axis %d exponent %d", node, a, k);
         scale[a] = std::ldexp(1.0, k);
     }
     int present = 0;
-    for (int s = 0; s < 4; s++) {
+    for (int s = 0; s < 8; s++) {
         double lo[3], hi[3];
-        bool absent = false;
+        bool inverted = false;
         for (int a = 0; a < 3; a++) {
-            const uint32_t qlo = (n.qlo[a] >> (8 * s)) & 0xFFu, qhi = (n.qhi[a] >> (8 * s)) & 0xFFu;
-            if (qlo > qhi) absent = true;
+            const uint32_t qlo = (n.qlo[a][s >> 2] >> (8 * (s & 3))) & 0xFFu, qhi = (n.qhi[a][s >> 2] >> (8 * (s & 3))) & 0xFFu;
+            if (qlo > qhi) inverted = true;
             lo[a] = (double)n.org[a] + qlo * scale[a];
             hi[a] = (double)n.org[a] + qhi * scale[a];
         }
-        const uint32_t off = (child_off >> (4 * s)) & 15u;
-        const uint32_t ref = ((uint32_t)s < n_inner ? base_inner : base_leaf) + off;
-        if (absent) { // may be entered by a degenerate evaluation: must still be a readable leaf
-            CHECK((uint32_t)s >= n_inner, "node %u: inner slot %d is absent", node, s);
-            const uint32_t start = ref & RT_DEV_LEAF_START_MASK;
-            CHECK((ref & RT_DEV_LEAF_FLAG) && start < c.b->tris.size() && c.b->tris[start].leaf_count >= 1 &&
-                      (size_t)start + c.b->tris[start].leaf_count <= c.b->tris.size(),
-                  "node %u: absent slot %d decodes to an unreadable leaf (start %u)", node, s, start);
+        const bool inner = (imask >> s) & 1u, leaf = (lmask >> s) & 1u;
+        if (!inner && !leaf) {
+            CHECK(inverted, "node %u: empty slot %d has a box that can be entered", node, s);
             continue;
         }
+        CHECK(!inverted, "node %u: occupied slot %d has an inverted box", node, s);
         present++;
         if (have_box)
             for (int a = 0; a < 3; a++) { // a child's box may stick out of its parent's by the quantisation step, not more
                 CHECK(lo[a] >= plo[a] - 2 * scale[a] - 1e-30 && hi[a] <= phi[a] + 2 * scale[a] + 1e-30, "node %u slot %d axis %d box [%.9g,%.9g] far outside parent [%.9g,%.9g]",
                       node, s, a, lo[a], hi[a], plo[a], phi[a]);
             }
-        if (ref & RT_DEV_LEAF_FLAG) check_leaf(c, ref, lo, hi, true);
-        else check_node(c, ref, depth + 1, lo, hi, true);
+        const uint32_t below = (1u << s) - 1u;
+        if (leaf) check_leaf(c, n.tri_base + RT_DEV_LEAF_STRIDE * (uint32_t)__builtin_popcount(lmask & below), lo, hi, true);
+        else check_node(c, n.child_base + (uint32_t)__builtin_popcount(imask & below), depth + 1, lo, hi, true);
     }
-    CHECK(present >= 2, "node %u has %d children", node, present);
+    CHECK(present >= (node == 0 ? 1 : 2), "node %u has %d children", node, present);
 }
 
 int main(int argc, char** argv) {
@@ -148,15 +145,14 @@ int main(int argc, char** argv) {
     Ctx c;
     c.b = &b;
     c.seen.assign(n, 0);
-    CHECK(b.tris.size() == n_finite, "%zu triangles emitted, %zu finite", b.tris.size(), n_finite);
     const double inf = std::numeric_limits<double>::infinity();
     const double lo[3] = {-inf, -inf, -inf}, hi[3] = {inf, inf, inf};
     if (n_finite == 0) {
-        CHECK(b.nodes.empty() && b.root_ref == RT_DEV_REF_NONE, "empty build has nodes");
-    } else if (b.root_ref & RT_DEV_LEAF_FLAG) {
-        check_leaf(c, b.root_ref, lo, hi, false);
+        CHECK(b.nodes.empty() && b.tris.empty(), "empty build has nodes");
     } else {
-        check_node(c, b.root_ref, 1, lo, hi, false);
+        check_node(c, 0, 1, lo, hi, false);
+        CHECK(b.tris.size() == c.leaves * RT_DEV_LEAF_STRIDE, "%zu triangle records for %zu leaves", b.tris.size(), c.leaves);
+        CHECK(b.n_leaves == c.leaves, "n_leaves %u, found %zu", b.n_leaves, c.leaves);
     }
     size_t once = 0;
     for (size_t i = 0; i < n; i++) {
@@ -166,7 +162,7 @@ int main(int argc, char** argv) {
         once += c.seen[i] == 1;
     }
     CHECK(c.max_depth <= b.depth, "real depth %u exceeds the reported %u", c.max_depth, b.depth);
-    CHECK(3 * b.depth + 1 <= RT_DEV_MAX_STACK_ENTRIES, "depth %u needs more stack than the kernels provide", b.depth);
+    CHECK(2 * b.depth + 2 <= RT_DEV_MAX_STACK_ENTRIES, "depth %u needs more stack than the kernels provide", b.depth);
     std::printf("kind %d n %zu: %zu nodes, %zu leaves, depth %u (reported %u), %zu triangles placed, %d failures\n", kind, n, b.nodes.size(), c.leaves, c.max_depth,
                 b.depth, once, g_fail);
     return g_fail ? 1 : 0;

@@ -1,6 +1,6 @@
 """The device BVH builder (host code, gpu_raytracer_amd/csrc/bvh_builder.cpp) under AddressSanitizer + UBSan, checked by a
-structural validator that decodes nodes the way the kernels do (tests/check_bvh.cpp): reference validity including the
-slots of absent children, each triangle in exactly one leaf, conservative boxes, depth within the kernels' stack."""
+structural validator that decodes the 8-wide nodes the way the kernels do (tests/check_bvh.cpp): slot / mask consistency, empty
+slots inverted, each triangle in exactly one leaf, conservative boxes, depth within the kernels' stack."""
 import os
 import subprocess
 

@@ -1,5 +1,5 @@
 """Adversarial inputs for the HIP path (run with -m gpu): geometry and cameras chosen to stress what differs between
-this implementation and the reference's — the quantised, conservative BVH filter, the 4-wide collapse, the tie rule,
+this implementation and the reference's — the quantised, conservative BVH filter, the 8-wide collapse and its slot order, the tie rule,
 the stack, the queue machinery — while the arithmetic that decides hits and colours must stay bit-identical to the
 oracle's brute-force path (reference semantics) and to the CPU statement of the extended mode.
 """

@@ -134,22 +134,3 @@ def test_extended_image_independent_of_batching_and_tiles(rt_api, monkeypatch):
     for k, img in images.items():
         np.testing.assert_array_equal(img.view(np.uint32), ref.view(np.uint32), err_msg=k)
 
-
-def test_wavefront_8_wide_and_4_wide_trees_give_identical_frames(rt_api, monkeypatch):
-    """The queue pipeline's traversal kernels walk the 8-wide tree (DevNode8: octant-ordered groups, no distance sort);
-    RT_BVH8=0 makes them walk the 4-wide tree the other kernels use.  Closest hits are topology independent (ties go to
-    the lower triangle index), any-hit is a boolean: same bits, same segment counts; the 8-wide walk visits fewer nodes."""
-    scene = scenes.sponza_like()
-    w, h, spp, bounces = 320, 180, 4, 4
-    out = {}
-    for flag in ("0", "1"):
-        monkeypatch.setenv("RT_BVH8", flag)
-        with rt_api.Context() as ctx:
-            ctx.upload_scene(scene)  # the environment is read when the acceleration structures are built
-            st = ctx.render(w, h, scene.camera, mode=2, spp=spp, max_bounces=bounces, counters=True)
-            out[flag] = (ctx.read_rgb32f(), st)
-    (a, sa), (b, sb) = out["0"], out["1"]
-    np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
-    assert (sa["primary_rays"], sa["continuation_rays"], sa["shadow_rays"]) == (sb["primary_rays"], sb["continuation_rays"], sb["shadow_rays"])
-    assert sa["node_bytes"] == 48 and sb["node_bytes"] == 80
-    assert sb["node_visits"] < 0.8 * sa["node_visits"]

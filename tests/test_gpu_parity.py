@@ -187,7 +187,7 @@ def test_counters_and_stats(gpu_ctx, oracle_mod):
     gpu_ctx.upload_scene(scene)
     st = gpu_ctx.render(256, 160, scene.camera, counters=True)
     assert st["rays"] == st["pixels"] == 256 * 160 and st["kernel_ms"] > 0
-    assert st["node_bytes"] == 48 and st["tri_bytes"] == 48 and st["bvh_depth"] <= 32
+    assert st["node_bytes"] == 80 and st["tri_bytes"] == 48 and st["bvh_depth"] <= 32
     ref = oracle_mod.render_frame(oracle_mod.PackedScene(scene), 256, 160)
     # ordered traversal with culling visits far fewer nodes than the reference's pop-then-test walk
     assert 0 < st["node_visits"] < ref["counters"]["node_visits"]
@@ -257,7 +257,7 @@ def test_bistro_like_vs_faithful_oracle(gpu_ctx, oracle_mod):
     gpu = _render_gpu(gpu_ctx, scene, w, h, mode=1)
     _assert_bit_exact(gpu, ref)
     st = gpu["stats"]
-    assert st["bvh_depth"] <= 32 and st["bvh_nodes"] > 500_000
+    assert st["bvh_depth"] <= 32 and st["bvh_nodes"] > 200_000
     # full-size properties at 4K: idempotent, finite, most of the street block is covered
     gpu_ctx.render(3840, 2160, scene.camera, mode=1)
     a = gpu_ctx.read_rgb32f()
