@@ -172,6 +172,16 @@ class Context:
         names = ("transition_passes", "transition_lanes", "node_iters", "node_lanes", "leaf_iters", "leaf_lanes", "cycles_transition", "cycles_traversal")
         return dict(zip(names, [int(v) for v in out]))
 
+    def debug_check_bvh(self):
+        """Development aid: validate the tree this context holds on its first device the way the kernels decode it.
+        Returns dict(failures, nodes, leaves, depth, real_depth, placed_once, method) - method 0 host SAH, 1 host PLOC, 2 device build."""
+        out = (C.c_uint32 * 8)()
+        fails = self.lib.rt_debug_check_bvh(self._h, out)
+        names = ("nodes", "leaves", "depth", "real_depth", "placed_once", "method", "nodes_hash", "tris_hash")
+        d = dict(zip(names, [int(v) for v in out]))
+        d["failures"] = int(fails)
+        return d
+
     def stats(self):
         st = np.zeros((), dtype=T.STATS)
         self._check(self.lib.rt_get_stats(self._h, _p(st)))

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <future>
@@ -343,6 +344,104 @@ void put_tri(const BuildTri& t, DevTri* o) {
     o->leaf_count = 0;
 }
 
+// ---- PLOC (Meister, Bittner, "Parallel Locally-Ordered Clustering for Bounding Volume Hierarchy Construction", 2018): sort the
+// triangles along a Morton curve, then repeatedly merge every pair of clusters that are each other's nearest neighbour (by the
+// area of the union) within `radius` positions of the curve.  This host version is the executable statement of what the device
+// build does (csrc/device_build.hip); it fills `nodes` (leaves first: node i = the i-th triangle in Morton order) and returns the root.
+uint64_t morton21(float x) { // x in [0, 1]: 21 bits spread to every third bit (same expression in device_build.hip)
+    uint64_t v = (uint64_t)(uint32_t)std::min(std::max(x * 2097152.0f, 0.0f), 2097151.0f);
+    v = (v | v << 32) & 0x1f00000000ffffull;
+    v = (v | v << 16) & 0x1f0000ff0000ffull;
+    v = (v | v << 8) & 0x100f00f00f00f00full;
+    v = (v | v << 4) & 0x10c30c30c30c30c3ull;
+    v = (v | v << 2) & 0x1249249249249249ull;
+    return v;
+}
+
+uint32_t build_ploc(const std::vector<Box>& boxes, const std::vector<float>& cent, std::vector<uint32_t>& ids, std::vector<TmpNode>& nodes, uint32_t radius) {
+    const size_t n = ids.size();
+    Box cb;
+    cb.reset();
+    for (size_t i = 0; i < n; i++) cb.grow(&cent[3 * (size_t)ids[i]]);
+    float inv[3];
+    for (int a = 0; a < 3; a++) inv[a] = cb.mx[a] > cb.mn[a] ? 1.0f / (cb.mx[a] - cb.mn[a]) : 0.0f;
+    std::vector<std::pair<uint64_t, uint32_t>> keyed(n);
+    for (size_t i = 0; i < n; i++) {
+        const float* c = &cent[3 * (size_t)ids[i]];
+        const uint64_t code = (morton21((c[0] - cb.mn[0]) * inv[0]) << 2) | (morton21((c[1] - cb.mn[1]) * inv[1]) << 1) | morton21((c[2] - cb.mn[2]) * inv[2]);
+        keyed[i] = {code, ids[i]};
+    }
+    std::sort(keyed.begin(), keyed.end());
+    for (size_t i = 0; i < n; i++) ids[i] = keyed[i].second;
+    nodes.resize(2 * n);
+    std::vector<uint32_t> cl(n), nn(n), next;
+    for (size_t i = 0; i < n; i++) {
+        nodes[i].box = boxes[ids[i]];
+        nodes[i].left = nodes[i].right = 0xFFFFFFFFu;
+        nodes[i].start = (uint32_t)i;
+        nodes[i].count = 1;
+        cl[i] = (uint32_t)i;
+    }
+    uint32_t n_nodes = (uint32_t)n;
+    size_t m = n;
+    next.reserve(n);
+    // Degenerate input stalls the pairing: with coincident triangles every cluster's nearest neighbour is the first of its
+    // window, in a chain of growing triangles it is the predecessor - one mutual pair per round, and a tree as deep as the
+    // input is long.  A round that merges less than a sixteenth of the clusters therefore escalates, for the rest of the build:
+    // level 1 prefers position i ^ 1 among EQUAL areas (coincident triangles then pair up perfectly), level 2 pairs i and i ^ 1
+    // outright.  Ordinary scenes never leave level 0.  (Level 1's rule at level 0 was measured: +5 % node visits on the
+    // sponza-like scene, whose tessellated walls are full of exact ties.)
+    int level = 0;
+    while (m > 1) {
+        for (size_t i = 0; i < m; i++) {
+            const size_t buddy = i ^ 1;
+            if (level == 2) {
+                nn[i] = (uint32_t)(buddy < m ? buddy : i);
+                continue;
+            }
+            const Box& bi = nodes[cl[i]].box;
+            auto union_area = [&](size_t j) {
+                Box u = bi;
+                u.grow(nodes[cl[j]].box);
+                return u.half_area();
+            };
+            float best = std::numeric_limits<float>::infinity();
+            uint32_t bj = (uint32_t)i;
+            if (level == 1 && buddy < m) best = union_area(buddy), bj = (uint32_t)buddy;
+            const size_t lo = i > radius ? i - radius : 0, hi = std::min(m - 1, i + radius);
+            for (size_t j = lo; j <= hi; j++) { // first best: the lower position wins ties
+                if (j == i) continue;
+                const float a = union_area(j);
+                if (a < best) best = a, bj = (uint32_t)j;
+            }
+            nn[i] = bj;
+        }
+        next.clear();
+        const uint32_t nodes_before = n_nodes;
+        for (size_t i = 0; i < m; i++) {
+            const uint32_t j = nn[i];
+            if (j != i && nn[j] == i) {
+                if (i < j) {
+                    TmpNode& p = nodes[n_nodes];
+                    p.box = nodes[cl[i]].box;
+                    p.box.grow(nodes[cl[j]].box);
+                    p.left = cl[i];
+                    p.right = cl[j];
+                    p.start = p.count = 0;
+                    next.push_back(n_nodes++);
+                }
+            } else {
+                next.push_back(cl[i]);
+            }
+        }
+        if ((n_nodes - nodes_before) < m / 16 && level < 2) level++;
+        m = next.size();
+        std::copy(next.begin(), next.end(), cl.begin());
+    }
+    nodes.resize(n_nodes);
+    return cl[0];
+}
+
 // ---- 8-wide collapse (DevNode8).  Which binary nodes become wide nodes, which are absorbed, which subtrees become one leaf is
 // chosen by dynamic programming over the binary tree (minimum expected cost): c[k-1] = cheapest cost of a subtree when it may
 // occupy at most k child slots of its wide parent: k = 1: either one leaf (<= max_leaf triangles) or a wide node of its own,
@@ -418,7 +517,7 @@ void collapse8(std::vector<TmpNode>& nodes, std::vector<uint32_t>& ids, uint32_t
         return;
     }
     std::vector<Dp8> dp(n_nodes);
-    std::vector<uint32_t> sub_start(n_nodes, 0), sub_count(n_nodes, 0);
+    std::vector<uint32_t> sub_count(n_nodes, 0);
     const float inf = std::numeric_limits<float>::infinity();
     {
         struct Frame {
@@ -436,7 +535,6 @@ void collapse8(std::vector<TmpNode>& nodes, std::vector<uint32_t>& ids, uint32_t
                 const float lc = opt.cost_intersect * (float)t.count * t.box.half_area();
                 for (int k = 0; k < W8; k++) d.c[k] = lc, d.split[k] = 0;
                 d.leaf = 1;
-                sub_start[f.node] = t.start;
                 sub_count[f.node] = t.count;
                 continue;
             }
@@ -446,10 +544,9 @@ void collapse8(std::vector<TmpNode>& nodes, std::vector<uint32_t>& ids, uint32_t
                 st.push_back({t.right, 0});
                 continue;
             }
-            const uint32_t ls = sub_start[t.left], lc_ = sub_count[t.left], rs = sub_start[t.right], rc_ = sub_count[t.right];
-            const bool contiguous = lc_ && rc_ && (ls + lc_ == rs || rs + rc_ == ls);
-            sub_start[f.node] = contiguous ? std::min(ls, rs) : 0;
-            sub_count[f.node] = contiguous ? lc_ + rc_ : 0;
+            // triangles of the subtree (saturating well above max_leaf): a subtree of <= max_leaf triangles may become one leaf,
+            // whatever the order of its ids (the leaf gathers them)
+            sub_count[f.node] = std::min<uint32_t>(sub_count[t.left] + sub_count[t.right], 1u << 20);
             const Dp8 &dl = dp[t.left], &dr = dp[t.right];
             float dist[W8 + 1];
             uint8_t arg[W8 + 1];
@@ -482,11 +579,22 @@ void collapse8(std::vector<TmpNode>& nodes, std::vector<uint32_t>& ids, uint32_t
                 expand(t.right, k - i, ch, nch);
                 return;
             }
-            if (dp[m].leaf) {
-                t.start = sub_start[m];
-                t.count = sub_count[m];
-                std::sort(ids.begin() + t.start, ids.begin() + t.start + t.count,
-                          [&](uint32_t x, uint32_t y) { return tris_in[x].prim_id < tris_in[y].prim_id; });
+            if (dp[m].leaf) { // the whole subtree as one leaf: gather its triangles (appended to ids), in index order
+                uint32_t gathered[RT_DEV_LEAF_STRIDE], ng = 0, todo[2 * RT_DEV_LEAF_STRIDE], nt = 0;
+                todo[nt++] = m;
+                while (nt) {
+                    const TmpNode& u = nodes[todo[--nt]];
+                    if (u.left == 0xFFFFFFFFu) {
+                        for (uint32_t i = 0; i < u.count && ng < RT_DEV_LEAF_STRIDE; i++) gathered[ng++] = ids[u.start + i];
+                    } else {
+                        todo[nt++] = u.left;
+                        todo[nt++] = u.right;
+                    }
+                }
+                std::sort(gathered, gathered + ng, [&](uint32_t x, uint32_t y) { return tris_in[x].prim_id < tris_in[y].prim_id; });
+                t.start = (uint32_t)ids.size();
+                t.count = ng;
+                ids.insert(ids.end(), gathered, gathered + ng);
                 t.left = t.right = 0xFFFFFFFFu;
             }
         }
@@ -638,11 +746,17 @@ void build_bvh(const BuildTri* tris_in, size_t n_in, const BvhBuildOptions& opt_
     }
     size_t n = b.ids.size();
     if (n == 0) return;
+    if (opt_in.method == 1) { // PLOC on the host: the statement of the device build (quality / structure reference)
+        std::vector<TmpNode> pn;
+        const uint32_t proot = build_ploc(b.boxes, b.cent, b.ids, pn, opt_in.ploc_radius);
+        collapse8(pn, b.ids, (uint32_t)pn.size(), proot, tris_in, b.opt, b.opt.max_leaf, out);
+        return;
+    }
     b.nodes.resize(2 * n);
     uint32_t root = b.alloc();
     b.build(root, 0, (uint32_t)n, 0);
 #if RT_BVH_REINSERT
-    if (n > 8) { // keep the top-down tree when the optimised one would exceed the depth the kernels' stacks are sized for
+    if (n > 8 && opt_in.reinsert) { // keep the top-down tree when the optimised one would exceed the depth the kernels' stacks are sized for
         std::vector<TmpNode> keep(b.nodes.begin(), b.nodes.begin() + b.next_node.load());
         const uint32_t keep_root = root;
         const uint32_t d = reinsertion_optimize(b.nodes, b.next_node.load(), root, RT_BVH_REINSERT_PASSES, RT_BVH_REINSERT_FRACTION);

@@ -39,6 +39,9 @@ struct BvhBuildOptions {
     float cost_traverse = 0.7f; // of a BINARY node while the binary tree is built, relative to cost_intersect (measured optimum 0.5-0.75)
     float cost_intersect = 1.0f;
     float cost_traverse8 = 1.0f; // of an 8-wide node in the collapse (0.7 ... 1.5 measure the same)
+    int method = 0;              // 0: binned SAH top-down + insertion-based optimisation (quality); 1: PLOC (what the device build does)
+    bool reinsert = true;        // method 0: run the insertion-based optimisation
+    uint32_t ploc_radius = 8;    // PLOC (host statement and device build): search radius along the Morton curve (8 / 16 / 32 measure within 1.5 %)
 };
 
 // Triangles with a non-finite coordinate are dropped: Möller–Trumbore can never accept

@@ -171,12 +171,17 @@ __device__ __forceinline__ bool test_leaf(const DevTri* __restrict__ tris, uint3
 // with a = scale/d, b = (org - o)/d the plane distances are fma(q, a, b), whose own absolute error
 // is below (2^-22 + 2^-23) * (|org - o| + 255 * scale) / |d| (one rounding each in org - o, a, b and the
 // fma, one ulp in v_rcp_f32).  Near planes are moved back and far planes forward by RT_FILTER_SLACK
-// (1e-6, 2.8 times that bound) times the same magnitude; the margin is there for the triangle test's
-// own rounding.  All parity tests (up to 3.8 M triangles, bit-exact against brute-force / mesh-order
-// oracles, adversarial scales and origins) pass with it.
+// (1e-5, 28 times that bound) times the same magnitude; the margin is there for the triangle test's
+// own rounding: Möller–Trumbore accepts rays that pass a few 1e-7 of their distance OUTSIDE a
+// triangle's exact box (a grazed edge whose triangle defines the node's face gets no help from the
+// quantisation).  Round 1's 1e-6 was too tight by a hair: at one ray in 2*10^9 of the headline frame the
+// result depended on the tree (found in round 2 when a second builder produced other boxes).  With 1e-5
+// every builder gives the same frame, the one the reference's brute-force path gives - the reference's
+// own BVH walk, whose slab test has no margin at all, misses that triangle (tests/test_oracle_extended.py
+// pins the pixel).  The wider margin costs nothing measurable (it is far below the quantisation step).
 // ------------------------------------------------------------------------------------
 #ifndef RT_FILTER_SLACK
-#define RT_FILTER_SLACK 1.0e-6f
+#define RT_FILTER_SLACK 1.0e-5f
 #endif
 #ifndef RT_FILTER_RCP
 #define RT_FILTER_RCP 1 /* round 2: -1 % on the headline frame; the error bound above includes its one ulp */

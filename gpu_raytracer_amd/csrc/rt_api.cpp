@@ -17,10 +17,14 @@
 
 #include "../../include/rt_hip.h"
 #include "bvh_builder.h"
+#include "bvh_check.h"
+#include "device_build.h"
 #include "device_layout.h"
 #include "half.h"
 #include "kernels.h"
 #include "wavefront.h"
+
+#define RT_DEVICE_BUILD_MIN_TRIS 1024u /* below this the host build takes well under a millisecond */
 
 namespace {
 
@@ -65,6 +69,8 @@ struct rt_ctx {
     bool frame_valid = false;
     unsigned long long diag[8] = {0}; // diagnostics of the counting kernel variant (rt_debug_counters)
     int fail_upload_at = -1;          // test hook: the next scene upload fails before its k-th device array (rt_debug_fail_upload)
+    uint32_t n_input_tris = 0;        // triangles handed to the last scene upload (prim ids are < this)
+    int build_method = 0;             // how its tree was built: 0 host SAH, 1 host PLOC, 2 device PLOC
     uint32_t n_textures = 0;          // bindings 6-7 as last handed over (rt_upload_textures); never sampled, like the reference
     uint64_t texture_bytes = 0;
 
@@ -224,12 +230,62 @@ int upload_common(rt_ctx* ctx, const rt_sphere* spheres, uint32_t n_spheres, con
     if (const char* e = std::getenv("RT_BVH_COST_TRAVERSE")) opt.cost_traverse = (float)std::atof(e); // tuning knobs (development)
     if (const char* e = std::getenv("RT_BVH_MAX_LEAF")) opt.max_leaf = (uint32_t)std::atoi(e);
     if (const char* e = std::getenv("RT_BVH8_COST_TRAVERSE")) opt.cost_traverse8 = (float)std::atof(e);
-    double t0 = now_ms();
-    rt::build_bvh(bt.data(), bt.size(), opt, bvh);
-    double build_ms = now_ms() - t0;
-    (void)build_ms;
-    if (bvh.depth > RT_DEV_MAX_BVH_DEPTH) return ctx->fail(RT_ERR_INTERNAL, "BVH depth %u exceeds the bound %d", bvh.depth, RT_DEV_MAX_BVH_DEPTH);
-    if (bvh.nodes.size() > RT_DEV_MAX_NODES) return ctx->fail(RT_ERR_BAD_ARG, "scene needs %zu BVH nodes > %u", bvh.nodes.size(), RT_DEV_MAX_NODES);
+    if (const char* e = std::getenv("RT_BUILD_METHOD")) opt.method = std::atoi(e);
+    if (const char* e = std::getenv("RT_BUILD_REINSERT")) opt.reinsert = std::atoi(e) != 0;
+    if (const char* e = std::getenv("RT_PLOC_RADIUS")) opt.ploc_radius = (uint32_t)std::atoi(e);
+    // Where the tree is built.  Default (method 2): ON the device (device_build.hip: Morton sort + PLOC + collapse + emission,
+    // a few milliseconds), as soon as the scene is large enough for that to matter; the host builders remain for tiny scenes, as
+    // the fallback when a device-built tree would be deeper than the kernels' stacks allow (degenerate inputs; the host build
+    // bounds its depth), and on request: RT_BUILD_METHOD=0 binned SAH + insertion-based optimisation (1 % faster frames, 0.35 s
+    // per 262 k triangles), 1 PLOC on the host (the statement the device build is checked against).
+    int method = 2;
+    if (const char* e = std::getenv("RT_BUILD_METHOD")) method = std::atoi(e);
+    if (method == 2 && bt.size() < RT_DEVICE_BUILD_MIN_TRIS) method = 0;
+    opt.method = method == 1 ? 1 : 0;
+    std::vector<rt::DeviceBuild> dbuilds;
+    uint32_t tree_nodes = 0, tree_tris = 0, tree_depth = 0;
+    if (method == 2) {
+        if (ctx->fail_upload_at == 0) {
+            ctx->fail_upload_at = -1;
+            ctx->uploaded = false;
+            ctx->frame_valid = false;
+            ctx->scene_counts = DevScene{};
+            for (auto& d : ctx->devs) free_scene(d);
+            return ctx->fail(RT_ERR_OOM, "rt_upload: allocation failure injected by rt_debug_fail_upload");
+        }
+        dbuilds.resize(ctx->devs.size());
+        bool ok = true;
+        for (size_t j = 0; j < ctx->devs.size() && ok; j++) {
+            DeviceState& d = ctx->devs[j];
+            HIPCHK(ctx, hipSetDevice(d.device));
+            const hipError_t e = rt::device_build(bt.data(), bt.size(), opt, d.stream, &dbuilds[j]);
+            ok = e == hipSuccess && dbuilds[j].depth <= RT_DEV_MAX_BVH_DEPTH && dbuilds[j].n_nodes <= RT_DEV_MAX_NODES &&
+                 dbuilds[j].n_nodes == dbuilds[0].n_nodes && dbuilds[j].n_tris == dbuilds[0].n_tris;
+        }
+        if (!ok) { // fall back to the host build (depth bound, or the device ran out of memory for the temporaries)
+            for (size_t j = 0; j < dbuilds.size(); j++) {
+                (void)hipSetDevice(ctx->devs[j].device);
+                (void)hipFree(dbuilds[j].nodes);
+                (void)hipFree(dbuilds[j].tris);
+            }
+            dbuilds.clear();
+            method = 0;
+        } else {
+            tree_nodes = dbuilds[0].n_nodes;
+            tree_tris = dbuilds[0].n_tris;
+            tree_depth = dbuilds[0].depth;
+        }
+    }
+    if (method != 2) {
+        rt::build_bvh(bt.data(), bt.size(), opt, bvh);
+        if (bvh.depth > RT_DEV_MAX_BVH_DEPTH) return ctx->fail(RT_ERR_INTERNAL, "BVH depth %u exceeds the bound %d", bvh.depth, RT_DEV_MAX_BVH_DEPTH);
+        if (bvh.nodes.size() > RT_DEV_MAX_NODES) return ctx->fail(RT_ERR_BAD_ARG, "scene needs %zu BVH nodes > %u", bvh.nodes.size(), RT_DEV_MAX_NODES);
+        tree_nodes = (uint32_t)bvh.nodes.size();
+        tree_tris = (uint32_t)bvh.tris.size();
+        tree_depth = bvh.depth;
+    }
+    ctx->n_input_tris = (uint32_t)bt.size();
+    ctx->build_method = method;
 
     std::vector<DevSphere> ds(n_spheres);
     for (uint32_t i = 0; i < n_spheres; i++) {
@@ -278,10 +334,17 @@ int upload_common(rt_ctx* ctx, const rt_sphere* spheres, uint32_t n_spheres, con
         int rc;
         int k = 0;
         auto hook = [&]() { return ctx->fail_upload_at >= 0 && ctx->fail_upload_at == k++; }; // test hook (rt_debug_fail_upload)
+        const size_t j = (size_t)(&d - ctx->devs.data());
         if (hook()) return ctx->fail(RT_ERR_OOM, "rt_upload: allocation failure injected by rt_debug_fail_upload");
-        if ((rc = upload_array(ctx, &d.nodes, bvh.nodes)) != RT_OK) return rc;
+        if (!dbuilds.empty()) { // the tree was built on this device: take the arrays over
+            d.nodes = dbuilds[j].nodes;
+            dbuilds[j].nodes = nullptr;
+        } else if ((rc = upload_array(ctx, &d.nodes, bvh.nodes)) != RT_OK) return rc;
         if (hook()) return ctx->fail(RT_ERR_OOM, "rt_upload: allocation failure injected by rt_debug_fail_upload");
-        if ((rc = upload_array(ctx, &d.tris, bvh.tris)) != RT_OK) return rc;
+        if (!dbuilds.empty()) {
+            d.tris = dbuilds[j].tris;
+            dbuilds[j].tris = nullptr;
+        } else if ((rc = upload_array(ctx, &d.tris, bvh.tris)) != RT_OK) return rc;
         if (hook()) return ctx->fail(RT_ERR_OOM, "rt_upload: allocation failure injected by rt_debug_fail_upload");
         if ((rc = upload_array(ctx, &d.spheres, ds)) != RT_OK) return rc;
         if ((rc = upload_array(ctx, &d.lights, dl)) != RT_OK) return rc;
@@ -295,25 +358,30 @@ int upload_common(rt_ctx* ctx, const rt_sphere* spheres, uint32_t n_spheres, con
         if (rc != RT_OK) {
             ctx->fail_upload_at = -1;
             for (auto& e : ctx->devs) free_scene(e);
+            for (size_t j = 0; j < dbuilds.size(); j++) { // device-built arrays not yet handed to a device state
+                (void)hipSetDevice(ctx->devs[j].device);
+                (void)hipFree(dbuilds[j].nodes);
+                (void)hipFree(dbuilds[j].tris);
+            }
             return rc;
         }
     }
     ctx->fail_upload_at = -1;
     DevScene& sc = ctx->scene_counts;
     sc = DevScene{};
-    sc.n_nodes = (uint32_t)bvh.nodes.size();
-    sc.n_tris = (uint32_t)bvh.tris.size();
+    sc.n_nodes = tree_nodes;
+    sc.n_tris = tree_tris;
     sc.n_spheres = n_spheres;
     sc.n_lights = n_lights;
     sc.n_materials = n_materials;
-    sc.stack_entries = 2u * bvh.depth + 2u; // a visit parks at most two groups
+    sc.stack_entries = 2u * tree_depth + 2u; // a visit parks at most two groups
     ctx->stats = rt_stats{};
     ctx->stats.node_bytes = sizeof(DevNode8);
     ctx->stats.tri_bytes = sizeof(DevTri);
-    ctx->stats.scene_bytes = bvh.nodes.size() * sizeof(DevNode8) + bvh.tris.size() * sizeof(DevTri) + ds.size() * sizeof(DevSphere) +
+    ctx->stats.scene_bytes = (size_t)tree_nodes * sizeof(DevNode8) + (size_t)tree_tris * sizeof(DevTri) + ds.size() * sizeof(DevSphere) +
                              dl.size() * sizeof(DevLight) + dm.size() * sizeof(DevMaterial);
     ctx->stats.bvh_nodes = sc.n_nodes;
-    ctx->stats.bvh_depth = bvh.depth;
+    ctx->stats.bvh_depth = tree_depth;
     ctx->stats.n_devices = (uint32_t)ctx->devs.size();
     ctx->stats.n_textures = ctx->n_textures;
     ctx->stats.texture_bytes = ctx->texture_bytes;
@@ -735,6 +803,51 @@ int rt_debug_fail_upload(rt_ctx* ctx, int k) {
     if (!ctx) return RT_ERR_BAD_ARG;
     ctx->fail_upload_at = k;
     return RT_OK;
+}
+
+// Development aid (not part of rt_hip.h): download the tree the context holds on its first device and validate it the way the
+// kernels decode it (bvh_check.h: slots and masks, every finite triangle in exactly one leaf, conservative boxes, depth).
+// out[0] nodes, [1] leaves, [2] reported depth, [3] real depth, [4] triangles placed exactly once, [5] build method, [6] / [7] FNV-1a
+// hashes of the node and triangle arrays (the device build lays its tree out exactly as its host statement does); returns the number of failures.
+int rt_debug_check_bvh(rt_ctx* ctx, uint32_t out[8]) {
+    if (!ctx || !ctx->uploaded) return -1;
+    DeviceState& d = ctx->devs[0];
+    if (hipSetDevice(d.device) != hipSuccess) return -1;
+    (void)hipStreamSynchronize(d.stream);
+    rt::BvhBuild b;
+    b.nodes.resize(ctx->scene_counts.n_nodes);
+    b.tris.resize(ctx->scene_counts.n_tris);
+    if (!b.nodes.empty() && hipMemcpy(b.nodes.data(), d.nodes, b.nodes.size() * sizeof(DevNode8), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (!b.tris.empty() && hipMemcpy(b.tris.data(), d.tris, b.tris.size() * sizeof(DevTri), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    b.depth = ctx->stats.bvh_depth;
+    b.n_leaves = (uint32_t)(b.tris.size() / RT_DEV_LEAF_STRIDE);
+    std::vector<uint32_t> seen(ctx->n_input_tris, 0);
+    uint32_t real_depth = 0;
+    size_t leaves = 0;
+    rtcheck::g_print = true;
+    int fails = rtcheck::check_tree(b, seen, &real_depth, &leaves);
+    uint32_t once = 0;
+    for (uint32_t v : seen) {
+        once += v == 1 ? 1u : 0u;
+        if (v > 1) fails++;
+    }
+    if (out) {
+        out[0] = (uint32_t)b.nodes.size();
+        out[1] = (uint32_t)leaves;
+        out[2] = b.depth;
+        out[3] = real_depth;
+        out[4] = once;
+        out[5] = (uint32_t)ctx->build_method;
+        auto fnv = [](const void* p, size_t n) {
+            uint32_t h = 2166136261u;
+            const unsigned char* c = static_cast<const unsigned char*>(p);
+            for (size_t i = 0; i < n; i++) h = (h ^ c[i]) * 16777619u;
+            return h;
+        };
+        out[6] = fnv(b.nodes.data(), b.nodes.size() * sizeof(DevNode8));
+        out[7] = fnv(b.tris.data(), b.tris.size() * sizeof(DevTri));
+    }
+    return fails;
 }
 
 // Development aids (not part of rt_hip.h): the queue allocation bound and the window rule, host-only arithmetic (tests/test_queue_bound.py).

@@ -24,10 +24,13 @@ def checker(tmp_path_factory):
 KINDS = {0: "soup", 1: "coplanar", 2: "coincident points", 3: "collinear chain", 4: "huge + tiny", 5: "NaN / inf vertices"}
 
 
+@pytest.mark.parametrize("method", [0, 1], ids=["binned_sah", "ploc"])
 @pytest.mark.parametrize("kind", sorted(KINDS))
-def test_device_bvh_structure(checker, kind):
+def test_device_bvh_structure(checker, kind, method):
+    """method 1 is the host statement of the device build (device_build.hip): PLOC must stay logarithmic in rounds and shallow
+    enough for the kernels' stacks on coincident points and on chains, where its nearest-neighbour rule degenerates."""
     env = dict(os.environ, UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
     for n in (0, 1, 2, 5, 37, 1000, 20000):
-        run = subprocess.run([checker, str(n), str(17 * kind + n), str(kind)], capture_output=True, text=True, env=env, timeout=300)
+        run = subprocess.run([checker, str(n), str(17 * kind + n), str(kind), str(method)], capture_output=True, text=True, env=env, timeout=300)
         assert run.returncode == 0, f"{KINDS[kind]} n={n}:\n{run.stdout[-2000:]}\n{run.stderr[-3000:]}"
         assert " 0 failures" in run.stdout
