@@ -573,7 +573,10 @@ __global__ __launch_bounds__(WAVE, RT_SM_MIN_WAVES) void k_render_extended_sm(De
 
 namespace rt {
 
-static size_t lds_bytes(const DevScene& sc) { return (size_t)(sc.stack_entries ? sc.stack_entries : 1u) * WAVE * sizeof(uint2); }
+// The one-ray-per-lane walks park only the group of siblings still to visit (a node's leaves are tested right after its visit),
+// one entry per level: half of DevScene::stack_entries, which is sized for the queue pipeline's walk (it also parks postponed leaf
+// groups).  At 512 bytes per entry and wave this decides how many waves fit a CU: depth 11 -> 6 KB, 26 waves per CU.
+static size_t lds_bytes(const DevScene& sc) { return (size_t)(sc.stack_entries / 2u + 1u) * WAVE * sizeof(uint2); }
 
 __global__ __launch_bounds__(256) void k_combine_rgba8(const uint32_t* __restrict__ red, const uint32_t* __restrict__ green, const uint32_t* __restrict__ blue,
                                                         uint32_t* __restrict__ out, size_t n) {
