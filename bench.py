@@ -367,7 +367,7 @@ def main():
                                "carries path state only; see `issue`",
             "note": "launch = one frame on rank 0 (all stage kernels, HIP events on the launch stream).  achieved/frac: HBM-side bytes "
                     "from the committed PMC passes of this very build (FETCH_SIZE is uncalibrated for 16-byte gathers, "
-                    "MI355X_MICROARCH.md).  algorithmic_*: SURVEY 8d's per-segment figure (node fetches x 48 B + triangle fetches x "
+                    "MI355X_MICROARCH.md).  algorithmic_*: SURVEY 8d's per-segment figure (node fetches x 80 B + triangle fetches x "
                     "48 B + per-kind path state + pixels x 36 B); ~90 % of it is served by L1/L2, so it is a rate, not an HBM fraction",
         }
         if wavefront and diag[3] > 0:
