@@ -1,6 +1,6 @@
 // device_common.h — device-side building blocks shared by kernels.hip (megakernels) and wavefront.hip
 // (queue-based pipeline): vector math in the reference's operation order, ray generation, sphere and
-// Möller–Trumbore tests, the quantised 4-wide BVH visit, the reference's shading, and the extended mode's
+// Möller–Trumbore tests, the quantised 8-wide BVH visit and group walk, the reference's shading, and the extended mode's
 // RNG / sampling helpers.  Everything is __forceinline__; both translation units are compiled with
 // -ffp-contract=off so the arithmetic that decides hits and colours is identical in all kernels.
 #ifndef RT_DEVICE_COMMON_H

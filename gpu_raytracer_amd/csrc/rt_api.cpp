@@ -63,7 +63,7 @@ struct rt_ctx {
     std::string err;
     bool uploaded = false;
     bool pending_dispatch = false; // rt_dispatch_tile launches are not waited for (the reference's queue.submit is not either); see sync_pending
-    DevScene scene_counts{}; // counts + root_ref; pointers are per device
+    DevScene scene_counts{}; // counts; pointers are per device
     rt_stats stats{};
     uint32_t frame_w = 0, frame_h = 0, frame_tile = RT_TILE_SIZE, frame_tiles_x = 0, frame_tiles_y = 0;
     bool frame_valid = false;

@@ -19,24 +19,15 @@
 
 using namespace rtdev;
 
-#ifndef RT_WF_MIN_WAVES
-#define RT_WF_MIN_WAVES 6 /* waves per SIMD the traversal kernels are register-allocated for */
-#endif
 #ifndef RT_WF_REFILL
 #define RT_WF_REFILL 16 /* idle lanes in a wave before it fetches new segments */
 #endif
 #ifndef RT_WF_CHUNK
-#define RT_WF_CHUNK 256 /* queue entries a wave claims per atomic */
-#endif
-#ifndef RT_WF_CHUNK_MAX
-#define RT_WF_CHUNK_MAX 256 /* ... at most.  Larger (guided) chunks were slower: 512 same, 1024 -1.5 %, 2048 -5 %, 8192 -12 %: small chunks keep the
-                               waves on neighbouring parts of the queue, i.e. on neighbouring rays, and the cursor atomics are not the bound */
+#define RT_WF_CHUNK 256 /* queue entries a wave claims per atomic (64 / 128: -37 % / -6 %, cursor atomics; 1024 / 2048 / 8192: -1.5 / -5 / -12 %: small chunks keep the
+                           waves on neighbouring parts of the queue, i.e. on neighbouring rays) */
 #endif
 #ifndef RT_WF_WINDOW
 #define RT_WF_WINDOW 512 /* queue slots a producing wave reserves per atomic */
-#endif
-#ifndef RT_WF_LEAF_THRESHOLD
-#define RT_WF_LEAF_THRESHOLD 24 /* lanes holding a postponed leaf before the triangle tests run */
 #endif
 #ifndef RT_WF_BLOCK_MAJOR
 #define RT_WF_BLOCK_MAJOR 1 /* path slots: all samples of a pixel block adjacent (1) or all blocks of a sample adjacent (0) */
@@ -44,16 +35,12 @@ using namespace rtdev;
 #ifndef RT_WF_SHADE_WAVES
 #define RT_WF_SHADE_WAVES 4 /* waves per SIMD the shading stages are register-allocated for */
 #endif
-#ifndef RT_WF_LEAF_POLICY
-#define RT_WF_LEAF_POLICY 0 /* 0: triangle tests run when RT_WF_LEAF_THRESHOLD lanes hold a leaf; 1: when that many lanes are blocked on theirs */
-#endif
 #ifndef RT_WF_WAVES_PER_CU
 #define RT_WF_WAVES_PER_CU 24
 #endif
 #ifndef RT_WF_SHADOW_LIGHT_MAJOR
 #define RT_WF_SHADOW_LIGHT_MAJOR 1
 #endif
-#define WF_REF_NONE RT_DEV_REF_NONE /* nothing left to visit */
 
 namespace {
 
