@@ -2,6 +2,11 @@
 
 -ffp-contract=off: the kernels keep the reference's f32 operation order (see kernels.hip);
 HIP's default correctly-rounded f32 divide/sqrt is left on.
+-fno-slp-vectorize: the SLP vectoriser pairs scalar f32 operations of the triangle test and the shading code into v_pk_* at the
+price of register moves to line the pairs up: 72 instead of 80 VGPRs and 2.3 % less frame time without it (profiles/ab_r02.json);
+the packed operations of the box test are written out in device_common.h and stay.
+-mllvm -enable-post-misched=0: the traversal loops are VALU-issue bound with 6 waves per SIMD hiding latency; the post-RA
+machine scheduler's reordering costs 1 % there (same A/B).
 """
 import os
 import subprocess
@@ -11,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librt_hip.so")
 SOURCES = ["kernels.hip", "wavefront.hip", "device_build.hip", "rt_api.cpp", "bvh_builder.cpp", "rt_host_api.cpp"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-mllvm", "-enable-post-misched=0",
          "-Wall", "-Wno-unused-function", "-pthread", "-I" + os.path.join(HERE, "..", "include")]
 
 

@@ -56,7 +56,9 @@ struct WfBuffers {
 };
 
 #define WF_TOTAL_ERROR 15 /* totals[] slot: non-zero = a queue reservation did not fit; every later stage kernel of the frame returns at once */
+#ifndef RT_WF8_LDS_STACK
 #define RT_WF8_LDS_STACK 8 /* 64-bit traversal stack entries per lane kept in LDS by the persistent kernels; deeper ones overflow to HBM */
+#endif
 #define RT_WF_MAX_LIGHTS 32u /* visibility is one bit per light in a 32-bit word */
 #define RT_WF_ID_MASK 0x07FFFFFFu
 

@@ -289,13 +289,14 @@ __global__ __launch_bounds__(WAVE, RT_WF8_MIN_WAVES) void k_wf_trace(DevScene sc
         }
         for (;;) {
             // ---- fetch: lanes without a node take the next child of their group, or the next group off the stack
-            if (active && cur == WF8_NONE) {
+            if (cur == WF8_NONE) { // (idle lanes have empty groups and an empty stack: nothing happens)
                 if ((g_bits & 0xFFu) == 0u && sp > 0) {
                     const int k = sp - 1;
-                    uint2 e;
-                    if (__ballot(k >= RT_WF8_LDS_STACK) == 0ull) e = stack[k * WAVE]; // wave-uniform: the common case stays a plain ds_read_b64
-                    else if (k < RT_WF8_LDS_STACK) e = stack[k * WAVE];
-                    else e = ovf[(k - RT_WF8_LDS_STACK) * WAVE];
+                    // an unconditional ds_read_b64 (clamped index), overridden on the rare lanes whose top entry is in HBM: left to
+                    // itself the compiler merges the two loads into one flat load through a selected 64-bit generic address
+                    uint2 e = stack[min(k, RT_WF8_LDS_STACK - 1) * WAVE];
+                    asm volatile("" : "+v"(e.x), "+v"(e.y)); // (pins the LDS read in front of the branch)
+                    if (k >= RT_WF8_LDS_STACK) e = ovf[(k - RT_WF8_LDS_STACK) * WAVE];
                     if (!(e.x & WF8_KIND_T)) {
                         sp = k;
                         g_base = e.x;
@@ -312,9 +313,11 @@ __global__ __launch_bounds__(WAVE, RT_WF8_MIN_WAVES) void k_wf_trace(DevScene sc
                     cur = g_base + (uint32_t)__popc(__builtin_amdgcn_ubfe(g_bits, 8u, i)); // inner slots below i
                 }
             }
-            const bool can_node = active && cur != WF8_NONE;
-            const bool has_leaf = active && (t_bits & 0xFFu) != 0u;
-            const unsigned long long m_node = __ballot(can_node), m_leaf = __ballot(has_leaf);
+            // an idle lane has cur == WF8_NONE and empty groups, so these are plain compares: one v_cmp per mask (a ballot of a
+            // bool that went through control flow costs a v_cndmask + v_cmp round trip)
+            const bool can_node = cur != WF8_NONE;
+            const bool has_leaf = (t_bits & 0xFFu) != 0u;
+            const unsigned long long m_node = __builtin_amdgcn_uicmp(cur, WF8_NONE, 33 /* ne */), m_leaf = __builtin_amdgcn_uicmp(t_bits & 0xFFu, 0u, 33);
             if (m_node != 0ull && __popcll(m_leaf) < RT_WF8_LEAF_THRESHOLD) {
                 if (COUNT) d_node_steps++;
                 if (can_node) {
@@ -362,7 +365,8 @@ __global__ __launch_bounds__(WAVE, RT_WF8_MIN_WAVES) void k_wf_trace(DevScene sc
                     d_leaf_trips += trips;
                 }
             }
-            if (active && cur == WF8_NONE && (g_bits & 0xFFu) == 0u && (t_bits & 0xFFu) == 0u && sp == 0) { // segment finished
+            const uint32_t busy = ((g_bits | t_bits) & 0xFFu) | (uint32_t)sp | (cur + 1u); // 0: nothing left to visit (and 0 on idle lanes)
+            if (active && busy == 0u) { // segment finished
                 if (ANY) {
                     if (hit.prim == RT_PRIM_MISS) atomicOr(reinterpret_cast<uint32_t*>(&wb.vtx_n[id]) + 3, 1u << li);
                 } else {
@@ -372,7 +376,7 @@ __global__ __launch_bounds__(WAVE, RT_WF8_MIN_WAVES) void k_wf_trace(DevScene sc
                 }
                 active = false;
             }
-            const unsigned long long still = __ballot(active);
+            const unsigned long long still = __builtin_amdgcn_uicmp(busy, 0u, 33 /* ne */);
             if (still == 0ull) break;
             if (!exhausted && __popcll(~still) >= RT_WF_REFILL) break;
         }
