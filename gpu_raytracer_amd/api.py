@@ -21,6 +21,7 @@ FLAG_COUNTERS = 1
 FLAG_NO_SHADOWS = 2
 FLAG_KERNEL_V1 = 4
 FLAG_KERNEL_SM = 8
+FLAG_NO_SHADOW_GRID = 16
 EXTENDED_AVAILABLE = True
 
 # every symbol include/rt_hip.h declares
@@ -128,12 +129,12 @@ class Context:
 
     # -- rendering -------------------------------------------------------------------
     def render(self, width, height, camera, mode=MODE_LEGACY, spp=1, max_bounces=4, frame_seed=0, tile_size=0,
-               tile_rank=0, tile_world=1, counters=False, no_shadows=False, kernel_v1=False, kernel_sm=False):
+               tile_rank=0, tile_world=1, counters=False, no_shadows=False, kernel_v1=False, kernel_sm=False, no_shadow_grid=False):
         p = np.zeros((), dtype=T.RENDER_PARAMS)
         p["camera"] = camera
         p["width"], p["height"], p["spp"], p["max_bounces"], p["mode"] = width, height, spp, max_bounces, mode
         p["frame_seed"], p["tile_size"], p["tile_rank"], p["tile_world"] = frame_seed, tile_size, tile_rank, tile_world
-        p["flags"] = (FLAG_COUNTERS if counters else 0) | (FLAG_NO_SHADOWS if no_shadows else 0) | (FLAG_KERNEL_V1 if kernel_v1 else 0) | (FLAG_KERNEL_SM if kernel_sm else 0)
+        p["flags"] = (FLAG_COUNTERS if counters else 0) | (FLAG_NO_SHADOWS if no_shadows else 0) | (FLAG_KERNEL_V1 if kernel_v1 else 0) | (FLAG_KERNEL_SM if kernel_sm else 0) | (FLAG_NO_SHADOW_GRID if no_shadow_grid else 0)
         self._check(self.lib.rt_render(self._h, _p(p)))
         self.width, self.height = width, height
         return self.stats()
@@ -170,6 +171,13 @@ class Context:
         out = (C.c_ulonglong * 8)()
         self._check(self.lib.rt_debug_counters(self._h, out))
         names = ("transition_passes", "transition_lanes", "node_iters", "node_lanes", "leaf_iters", "leaf_lanes", "cycles_transition", "cycles_traversal")
+        return dict(zip(names, [int(v) for v in out]))
+
+    def debug_shadow_grid(self, light=None):
+        """Development aid: the light grids (csrc/shadow_grid.h) of the first device.  light=None: totals and the last counted frame's use."""
+        out = (C.c_ulonglong * 8)()
+        self._check(self.lib.rt_debug_shadow_grid(self._h, C.c_uint32(0xFFFFFFFF if light is None else light), out))
+        names = ("lights_with_grid", "entries", "bytes", "segments_answered", "entries_read") if light is None else ("kind", "res", "entries", "near", "longest", "heavy_cells", "filled_cells")
         return dict(zip(names, [int(v) for v in out]))
 
     def debug_check_bvh(self):

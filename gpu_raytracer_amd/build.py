@@ -15,7 +15,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librt_hip.so")
-SOURCES = ["kernels.hip", "wavefront.hip", "device_build.hip", "rt_api.cpp", "bvh_builder.cpp", "rt_host_api.cpp"]
+SOURCES = ["kernels.hip", "wavefront.hip", "device_build.hip", "shadow_grid.hip", "rt_api.cpp", "bvh_builder.cpp", "rt_host_api.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-mllvm", "-enable-post-misched=0",
          "-Wall", "-Wno-unused-function", "-pthread", "-I" + os.path.join(HERE, "..", "include")]
 

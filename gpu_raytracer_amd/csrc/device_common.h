@@ -104,6 +104,24 @@ __device__ __forceinline__ void test_spheres(const DevScene& sc, V3 o, V3 d, Hit
 // src/bvh.rs:154-247) and its brute-force path (shader/src/lib.rs:283) do, and makes the
 // result independent of our own topology.
 // ------------------------------------------------------------------------------------
+// The arithmetic of TriangleIntersector::ray_triangle_intersect (shader/src/intersection.rs:91-138) up to the distance: false when
+// the ray is parallel (|a| < 1e-5) or passes outside (u, v); `t` is the distance along d otherwise (the callers apply the range).
+// One statement for the leaves of the BVH and for the light grids' lists (wavefront.hip), so both accept exactly the same rays.
+__device__ __forceinline__ bool moller_trumbore(V3 v0, V3 e1, V3 e2, V3 o, V3 d, float& t) {
+    V3 h = cross(d, e2);
+    float a = dot(e1, h);
+    if (fabsf(a) < RT_MIN_RAY_DISTANCE) return false;
+    float f = 1.0f / a;
+    V3 s = o - v0;
+    float u = f * dot(s, h);
+    if (u < 0.0f || u > 1.0f) return false;
+    V3 q = cross(s, e1);
+    float v = f * dot(d, q);
+    if (v < 0.0f || u + v > 1.0f) return false;
+    t = f * dot(e2, q);
+    return true;
+}
+
 // Returns the record's leaf_count word (the run length when `slot` is the first triangle of a leaf).
 __device__ __forceinline__ uint32_t test_triangle(const DevTri* __restrict__ tris, uint32_t slot, V3 o, V3 d, Hit& hit) {
     const float4* p = reinterpret_cast<const float4*>(tris + slot);
@@ -115,17 +133,8 @@ __device__ __forceinline__ uint32_t test_triangle(const DevTri* __restrict__ tri
     V3 v0 = v3(q0.x, q0.y, q0.z);
     V3 e1 = v3(q0.w, q1.x, q1.y);
     V3 e2 = v3(q1.z, q1.w, q2.x);
-    V3 h = cross(d, e2);
-    float a = dot(e1, h);
-    if (fabsf(a) < RT_MIN_RAY_DISTANCE) return leaf_count;
-    float f = 1.0f / a;
-    V3 s = o - v0;
-    float u = f * dot(s, h);
-    if (u < 0.0f || u > 1.0f) return leaf_count;
-    V3 q = cross(s, e1);
-    float v = f * dot(d, q);
-    if (v < 0.0f || u + v > 1.0f) return leaf_count;
-    float t = f * dot(e2, q);
+    float t;
+    if (!moller_trumbore(v0, e1, e2, o, d, t)) return leaf_count;
     uint32_t prim = __float_as_uint(q2.z);
     // equal t: the lower index wins among TRIANGLES only; against a sphere hit or the segment's own limit (prim = MISS, shadow
     // segments) the comparison stays strict, as in find_closest_intersection (lib.rs:214-248: the sphere is kept unless the

@@ -22,6 +22,7 @@
 #include "device_layout.h"
 #include "half.h"
 #include "kernels.h"
+#include "shadow_grid.h"
 #include "wavefront.h"
 
 #define RT_DEVICE_BUILD_MIN_TRIS 1024u /* below this the host build takes well under a millisecond */
@@ -49,6 +50,9 @@ struct DeviceState {
     void* readback_host = nullptr; // pinned staging for it
     size_t readback_bytes = 0;
     uint32_t tile_first = 0, tile_stride = 1, n_owned = 0; // of the last rt_render
+    DevShadowGrid* grids = nullptr;                        // one per light (shadow_grid.h), null when no light has a grid
+    std::vector<void*> grid_allocs;
+    std::vector<rt::ShadowGridBuild> grid_info;
     rt::WfBuffers wf{};                                    // wavefront pipeline state (extended mode)
     bool used_wavefront = false;
     uint32_t wf_lights = 0;
@@ -68,6 +72,7 @@ struct rt_ctx {
     uint32_t frame_w = 0, frame_h = 0, frame_tile = RT_TILE_SIZE, frame_tiles_x = 0, frame_tiles_y = 0;
     bool frame_valid = false;
     unsigned long long diag[8] = {0}; // diagnostics of the counting kernel variant (rt_debug_counters)
+    unsigned long long grid_diag[2] = {0}; // ... of the light grids: shadow segments they answered, list entries read
     int fail_upload_at = -1;          // test hook: the next scene upload fails before its k-th device array (rt_debug_fail_upload)
     uint32_t n_input_tris = 0;        // triangles handed to the last scene upload (prim ids are < this)
     int build_method = 0;             // how its tree was built: 0 host SAH, 1 host PLOC, 2 device PLOC
@@ -104,6 +109,10 @@ void free_scene(DeviceState& d) {
     (void)hipSetDevice(d.device);
     (void)hipFree(d.nodes); (void)hipFree(d.tris); (void)hipFree(d.spheres); (void)hipFree(d.lights); (void)hipFree(d.materials);
     d.nodes = nullptr; d.tris = nullptr; d.spheres = nullptr; d.lights = nullptr; d.materials = nullptr;
+    for (void* p : d.grid_allocs) (void)hipFree(p);
+    d.grid_allocs.clear();
+    d.grid_info.clear();
+    d.grids = nullptr;
 
 }
 void free_targets(DeviceState& d) {
@@ -329,6 +338,22 @@ int upload_common(rt_ctx* ctx, const rt_sphere* spheres, uint32_t n_spheres, con
     ctx->frame_valid = false;
     ctx->scene_counts = DevScene{};
     for (auto& d : ctx->devs) free_scene(d);
+    float box_lo[3] = {INFINITY, INFINITY, INFINITY}, box_hi[3] = {-INFINITY, -INFINITY, -INFINITY}; // of the triangles with finite vertices
+    for (const rt::BuildTri& t : bt) {
+        const float* vs[3] = {t.v0, t.v1, t.v2};
+        bool finite = true;
+        for (int k = 0; k < 3; k++)
+            for (int a = 0; a < 3; a++) finite = finite && std::isfinite(vs[k][a]);
+        if (!finite) continue;
+        for (int k = 0; k < 3; k++)
+            for (int a = 0; a < 3; a++) box_lo[a] = std::min(box_lo[a], vs[k][a]), box_hi[a] = std::max(box_hi[a], vs[k][a]);
+    }
+    bool grids_on = true;
+    rt::ShadowGridOptions gopt;
+    if (const char* e = std::getenv("RT_SHADOW_GRID")) grids_on = std::atoi(e) != 0;
+    if (const char* e = std::getenv("RT_SHADOW_GRID_RES")) gopt.res_point = (uint32_t)std::atoi(e), gopt.res_dir = 2u * (uint32_t)std::atoi(e); // development knobs
+    if (const char* e = std::getenv("RT_SHADOW_GRID_HEAVY")) gopt.heavy = (uint32_t)std::atoi(e);
+    if (const char* e = std::getenv("RT_SHADOW_GRID_MEAN")) gopt.max_mean_list = std::atof(e), gopt.max_heavy_share = 1.0; // (forces grids onto cluttered scenes)
     auto upload_all = [&](DeviceState& d) -> int {
         HIPCHK(ctx, hipSetDevice(d.device));
         int rc;
@@ -351,6 +376,34 @@ int upload_common(rt_ctx* ctx, const rt_sphere* spheres, uint32_t n_spheres, con
         if ((rc = upload_array(ctx, &d.materials, dm)) != RT_OK) return rc;
         // the copies went through the null stream and d.stream is non-blocking: make the order explicit
         HIPCHK(ctx, hipDeviceSynchronize());
+        // Per-light triangle lists for the shadow segments of the wavefront pipeline (shadow_grid.h), rasterised on the device from
+        // the triangle records just placed.  RT_SHADOW_GRID=0 switches them off (every shadow segment then walks the BVH).
+        if (grids_on && n_lights > 0 && n_lights <= RT_WF_MAX_LIGHTS && tree_tris > 0) {
+            std::vector<DevShadowGrid> hg(n_lights);
+            bool any = false;
+            size_t free_b = 0, total_b = 0;
+            HIPCHK(ctx, hipMemGetInfo(&free_b, &total_b));
+            rt::ShadowGridOptions lopt = gopt; // all grids together may take a quarter of what is free now
+            lopt.max_entries = std::min<uint64_t>(gopt.max_entries, free_b / 4 / n_lights / (RT_SG_ENTRY_QUADS * sizeof(uint4)));
+            for (uint32_t i = 0; i < n_lights; i++) {
+                rt::ShadowGridBuild gb;
+                const hipError_t e = rt::shadow_grid_build(d.tris, tree_tris, dl[i], box_lo, box_hi, lopt, d.stream, &gb);
+                if (e != hipSuccess) { // out of memory for a grid is not an error: the BVH answers for this light
+                    (void)hipGetLastError();
+                    gb = rt::ShadowGridBuild{};
+                }
+                hg[i] = gb.grid;
+                if (gb.cell_start) d.grid_allocs.push_back(gb.cell_start);
+                if (gb.entries) d.grid_allocs.push_back(gb.entries);
+                any = any || gb.grid.kind != RT_SG_KIND_NONE;
+                d.grid_info.push_back(gb);
+            }
+            if (any) {
+                if ((rc = upload_array(ctx, &d.grids, hg)) != RT_OK) return rc;
+                d.grid_allocs.push_back(d.grids);
+                HIPCHK(ctx, hipDeviceSynchronize());
+            }
+        }
         return RT_OK;
     };
     for (auto& d : ctx->devs) {
@@ -424,6 +477,7 @@ int ensure_wavefront(rt_ctx* ctx, DeviceState& d, uint32_t n_blocks, uint32_t ba
     HIPCHK(ctx, alloc((void**)&w.q_ext[0], ext_slots * 4));
     HIPCHK(ctx, alloc((void**)&w.q_ext[1], ext_slots * 4));
     HIPCHK(ctx, alloc((void**)&w.q_shadow, shadow_slots * 4));
+    HIPCHK(ctx, alloc((void**)&w.q_shadow2, (P * (size_t)lights + 64) * 4)); // written densely: one slot per entry
     w.q_ext_cap = (uint32_t)ext_slots;
     w.q_shadow_cap = (uint32_t)shadow_slots;
     HIPCHK(ctx, alloc((void**)&w.counters, rt::WF_N_COUNTERS * sizeof(uint32_t)));
@@ -530,6 +584,7 @@ int run_frame(rt_ctx* ctx, DevFrame fr, bool counters, uint32_t world, uint32_t 
             HIPCHK(ctx, hipMemsetAsync(d.wf.totals, 0, 16 * sizeof(unsigned long long), d.stream));
             HIPCHK(ctx, hipEventRecord(d.ev0, d.stream)); // re-record: allocation above is not part of the kernel time
             const DevScene dsc = scene_for(ctx, d);
+            d.wf.grids = (f.flags & RT_FLAG_NO_SHADOW_GRID) ? nullptr : d.grids;
             for (uint32_t first = 0; first < f.spp; first += batch) {
                 const uint32_t n = std::min(batch, f.spp - first);
                 HIPCHK(ctx, rt::wf_generate(dsc, f, d.wf, first, n, d.stream));
@@ -553,7 +608,7 @@ int run_frame(rt_ctx* ctx, DevFrame fr, bool counters, uint32_t world, uint32_t 
         HIPCHK(ctx, hipEventRecord(d.ev1, d.stream));
     }
     double kernel_ms = 0.0;
-    unsigned long long cnt[16] = {0};
+    unsigned long long cnt[16] = {0}, grid_cnt[2] = {0, 0};
     const bool extended = fr.mode == RT_MODE_EXTENDED;
     uint64_t pixels = 0;
     if (single_tile && !counters && !extended) { // one explicit tile of the reference's dispatch sequence: do not wait
@@ -589,6 +644,8 @@ int run_frame(rt_ctx* ctx, DevFrame fr, bool counters, uint32_t world, uint32_t 
             cnt[9] += t[6];
             cnt[10] += t[7];
             for (int k = 0; k < 5; k++) cnt[11 + k] += t[8 + k]; // wave-level step counts of the traversal stages
+            grid_cnt[0] += t[13];
+            grid_cnt[1] += t[14];
         } else if (counters || extended) {
             unsigned long long c[16];
             HIPCHK(ctx, hipMemcpy(c, d.counters, sizeof c, hipMemcpyDeviceToHost));
@@ -621,6 +678,7 @@ int run_frame(rt_ctx* ctx, DevFrame fr, bool counters, uint32_t world, uint32_t 
     st.node_visits = counters ? cnt[1] : 0;
     st.tri_tests = counters ? cnt[2] : 0;
     for (int k = 0; k < 8; k++) ctx->diag[k] = counters ? cnt[8 + k] : 0;
+    for (int k = 0; k < 2; k++) ctx->grid_diag[k] = counters ? grid_cnt[k] : 0;
     st.kernel_ms = kernel_ms;
     st.wall_ms = now_ms() - w0;
     st.flags = fallback ? RT_STAT_MEGAKERNEL_FALLBACK : 0u;
@@ -1081,6 +1139,37 @@ int rt_read_hits(rt_ctx* ctx, uint32_t* prim_ids, float* t, size_t n_pixels) {
 int rt_debug_counters(rt_ctx* ctx, unsigned long long out[8]) {
     if (!ctx || !out) return RT_ERR_BAD_ARG;
     for (int k = 0; k < 8; k++) out[k] = ctx->diag[k];
+    return RT_OK;
+}
+
+// Development aid: what the light grids (shadow_grid.h) of the first device look like.  light < n_lights: out = {kind (0: refused), cells per
+// side, entries, near-list length, longest list, cells left to the BVH, cells with a list, 0}; light == 0xFFFFFFFF: out = {lights with a grid, all
+// entries, bytes, shadow segments the grids answered in the last frame rendered with RT_FLAG_COUNTERS, list entries read, 0, 0, 0}.
+int rt_debug_shadow_grid(rt_ctx* ctx, uint32_t light, unsigned long long out[8]) {
+    if (!ctx || !out) return RT_ERR_BAD_ARG;
+    for (int k = 0; k < 8; k++) out[k] = 0;
+    if (ctx->devs.empty()) return RT_OK;
+    const DeviceState& d = ctx->devs[0];
+    if (light == 0xFFFFFFFFu) {
+        for (const rt::ShadowGridBuild& g : d.grid_info) {
+            if (g.grid.kind == RT_SG_KIND_NONE) continue;
+            out[0]++;
+            out[1] += g.n_entries;
+            out[2] += g.n_entries * RT_SG_ENTRY_QUADS * sizeof(uint4) + ((size_t)g.grid.n_cells + 2) * 4;
+        }
+        out[3] = ctx->grid_diag[0];
+        out[4] = ctx->grid_diag[1];
+        return RT_OK;
+    }
+    if (light >= d.grid_info.size()) return RT_OK;
+    const rt::ShadowGridBuild& g = d.grid_info[light];
+    out[0] = g.grid.kind;
+    out[1] = g.grid.res;
+    out[2] = g.n_entries;
+    out[3] = g.near_count;
+    out[4] = g.longest;
+    out[5] = g.heavy_cells;
+    out[6] = g.filled_cells;
     return RT_OK;
 }
 

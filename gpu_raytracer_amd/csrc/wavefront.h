@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include "device_layout.h"
+#include "shadow_grid.h"
 
 namespace rt {
 
@@ -19,13 +20,15 @@ namespace rt {
 enum WfCounter : uint32_t {
     WF_EXT_COUNT = 0,    // entries in the current extension queue
     WF_EXT_NEXT = 1,     // entries appended to the next extension queue
-    WF_UNUSED_2 = 2,
+    WF_SHADOW2_COUNT = 2, // shadow segments the light grids handed on to the BVH traversal (dense: no windows)
     WF_SHADOW_COUNT = 3, // shadow segments of this iteration
     WF_EXT_CURSOR = 4,   // persistent-kernel fetch cursors
     WF_SHADOW_CURSOR = 5,
     WF_EXT_WINDOW = 6,      // reservation window (a power of two) the current extension queue was written with
     WF_SHADOW_WINDOW = 7,   // ... the shadow queue
     WF_EXT_WINDOW_NEXT = 8, // ... the next extension queue
+    WF_SHADOW2_CURSOR = 9,
+    WF_SHADOW2_WINDOW = 10, // stays 0: the handed-on queue is written densely
     WF_N_COUNTERS = 12
 };
 
@@ -43,8 +46,10 @@ struct WfBuffers {
     // queues
     uint32_t* q_ext[2];  // path ids to extend (double buffered)
     uint32_t* q_shadow;  // path id | light << 27
+    uint32_t* q_shadow2; // the same entries, those the light grids (shadow_grid.h) leave to the BVH; dense
+    const DevShadowGrid* grids; // one per light, or null: every shadow segment walks the BVH
     uint32_t* counters;  // WfCounter
-    unsigned long long* totals; // [0] camera [1] continuation [2] shadow segments, [3] node visits, [4] triangle tests, [15] error word
+    unsigned long long* totals; // [0] camera [1] continuation [2] shadow segments, [3] node visits, [4] triangle tests, [13] shadow segments answered by a light grid, [14] list entries they read, [15] error word
     float4* accum;       // per owned pixel slot: running sum over samples (in sample order)
     uint32_t q_ext_cap;  // slots allocated for each extension queue / the shadow queue: a window reservation that would
     uint32_t q_shadow_cap; // end beyond it raises totals[WF_TOTAL_ERROR] instead of writing (window_reserve)

@@ -59,6 +59,8 @@ extern "C" {
 #define RT_FLAG_KERNEL_V1 4u  /* extended mode only: run the nested-loop megakernel (v1) instead of the   */
                               /* wavefront pipeline (A/B measurements; same results)                    */
 #define RT_FLAG_KERNEL_SM 8u  /* extended mode only: run the state-machine megakernel (v2) instead      */
+#define RT_FLAG_NO_SHADOW_GRID 16u /* extended mode only: every shadow segment walks the BVH instead of its  */
+                              /* light's triangle lists (A/B measurements and tests; same results)      */
 
 typedef struct rt_ctx rt_ctx;
 
