@@ -38,8 +38,8 @@ S_OUT_BYTES = 16 + 12 + 8  # per pixel: RGBA32F + three unorm8 texels + (prim id
 # Path-state bytes the queue pipeline moves per segment KIND (gpu_raytracer_amd/csrc/wavefront.hip; 16-byte records):
 #   extension segment (camera or continuation): written by generate/finish: ray_o, ray_d, thr, rad (64) + queue id (4);
 #     read by the closest-hit walk: id (4) + ray_o, ray_d (32), writes the hit record (16); the shade stage reads
-#     id + hit (20) and writes vtx_p, vtx_n (32); the finish stage reads id + vtx_p, vtx_n, thr, rad, ray_d (84)
-#   shadow segment: queue entry written and read (8) + vtx_p, vtx_n read (32) + one visibility bit (atomicOr, 4)
+#     id + hit (20) and writes the vertex record (32); the finish stage reads id + the vertex record, thr, rad, ray_d (84)
+#   shadow segment: queue entry written and read (8) + the vertex record read (32) + one visibility bit (atomicOr, 4)
 #   path: the sample's radiance written once and read once by the resolve (32) + pxy (4)
 S_STATE_EXTENSION = 64 + 4 + 4 + 32 + 16 + 20 + 32 + 84
 S_STATE_SHADOW = 8 + 32 + 4
@@ -327,10 +327,12 @@ def main():
     # exact node / triangle fetch counts and wave-level step statistics from the counting variant of the same kernels
     stc = step(counters=True)
     diag = list(ctx.debug_counters().values())
+    grid = ctx.debug_shadow_grid()  # the per-light triangle lists of the shadow stage (csrc/shadow_grid.h): what they hold and answered
     avg_kernel_ms = float(np.mean(kernel_ms))
     ext_segments = stc["primary_rays"] + stc["continuation_rays"]
     wavefront = mode_name == "extended" and args.kernel == "wavefront"
-    fetch_bytes = stc["node_visits"] * stc["node_bytes"] + stc["tri_tests"] * stc["tri_bytes"]
+    # (a triangle tested from a light's list is a 48-byte entry instead of a 48-byte record: the same figure; its cell costs 8 bytes more)
+    fetch_bytes = stc["node_visits"] * stc["node_bytes"] + stc["tri_tests"] * stc["tri_bytes"] + grid["segments_answered"] * 8
     state_bytes = (ext_segments * S_STATE_EXTENSION + stc["shadow_rays"] * S_STATE_SHADOW + stc["primary_rays"] * S_STATE_PATH) if wavefront else 0
     # SURVEY §8d's algorithmic bytes: every record fetch + the path state + the pixels.  The scene (23 MB) is cache
     # resident, so most of this never reaches HBM: it is reported as a rate, not as a fraction of the HBM peak.
@@ -357,14 +359,17 @@ def main():
             "traffic": traffic, "traffic_source": f"profiles/traffic.json@{prof['source_sha16']} ({prof.get('profile', '')})" if prof else None,
             "hbm_counter_frac": (traffic / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic is not None else None,
             "kernel": "k_render_reference" if mode_name == "reference" else
-                      "wavefront pipeline, all stage kernels of one frame (k_wf_trace<shadow> + k_wf_trace<closest> + k_wf_shade + k_wf_finish + k_wf_generate + k_wf_resolve)",
+                      "wavefront pipeline, all stage kernels of one frame (k_wf_shadow_grid + k_wf_trace<shadow> + k_wf_trace<closest> + k_wf_shade + k_wf_finish + k_wf_generate + k_wf_resolve)",
             "kernel_avg_ms": avg_kernel_ms,
             "compulsory_hbm_bytes_per_launch": compulsory_bytes,
             "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_GBps": alg_bytes / (avg_kernel_ms * 1e-3) / 1e9,
             "state_bytes_per_segment": {"extension": S_STATE_EXTENSION, "shadow": S_STATE_SHADOW, "path": S_STATE_PATH} if wavefront else None,
             "nodes_per_ray": stc["node_visits"] / max(stc["rays"], 1), "tris_per_ray": stc["tri_tests"] / max(stc["rays"], 1),
-            "practical_bound": "VALU issue of the two traversal kernels (branchy scalar f32, no MFMA): the scene is cache resident, HBM "
-                               "carries path state only; see `issue`",
+            "practical_bound": "VALU issue of the traversal kernels (branchy scalar f32, no MFMA; the tree is cache resident) and the rate of "
+                               "scattered line fetches of the light-grid stage (44-55 G lines/s measured, scripts/micro/random_read.hip); see `issue`",
+            "shadow_grids": {"lights_with_grid": grid["lights_with_grid"], "bytes": grid["bytes"], "entries": grid["entries"],
+                             "shadow_segments_answered_share": grid["segments_answered"] / max(stc["shadow_rays"], 1),
+                             "entries_read_per_answered_segment": grid["entries_read"] / max(grid["segments_answered"], 1)} if wavefront else None,
             "note": "launch = one frame on rank 0 (all stage kernels, HIP events on the launch stream).  achieved/frac: HBM-side bytes "
                     "from the committed PMC passes of this very build (FETCH_SIZE is uncalibrated for 16-byte gathers, "
                     "MI355X_MICROARCH.md).  algorithmic_*: SURVEY 8d's per-segment figure (node fetches x 80 B + triangle fetches x "

@@ -465,8 +465,7 @@ int ensure_wavefront(rt_ctx* ctx, DeviceState& d, uint32_t n_blocks, uint32_t ba
     HIPCHK(ctx, alloc((void**)&w.hit, P * 16));
     HIPCHK(ctx, alloc((void**)&w.thr, P * 16));
     HIPCHK(ctx, alloc((void**)&w.rad, P * 16));
-    HIPCHK(ctx, alloc((void**)&w.vtx_p, P * 16));
-    HIPCHK(ctx, alloc((void**)&w.vtx_n, P * 16));
+    HIPCHK(ctx, alloc((void**)&w.vtx, P * 32));
     HIPCHK(ctx, alloc((void**)&w.sample_rad, P * 16));
     HIPCHK(ctx, alloc((void**)&w.pxy, P * 4));
     // producers reserve queue space in windows (wavefront.hip): wf_queue_slots is the bound on real entries + padding

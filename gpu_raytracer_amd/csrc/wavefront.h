@@ -39,8 +39,9 @@ struct WfBuffers {
     uint4* hit;          // xyz = hit point bits, w = RT_PRIM_MISS | RT_PRIM_SPHERE_FLAG + sphere index | triangle slot
     float4* thr;         // xyz throughput, w = bits: hero channel | depth << 8
     float4* rad;         // xyz radiance of the sample so far, w = bits: rng state
-    float4* vtx_p;       // xyz vertex position, w = bits: material id
-    float4* vtx_n;       // xyz geometric normal, w = bits: light li is visible from the current vertex (set by the shadow stage)
+    float4* vtx;         // two per path, always used together, so one 32-byte record = one cache line per gather:
+                         //   [2 id]     xyz vertex position, w = bits: material id
+                         //   [2 id + 1] xyz geometric normal, w = bits: light li is visible from the current vertex (set by the shadow stage)
     float4* sample_rad;  // xyz final radiance of the sample (written when the path ends)
     uint32_t* pxy;       // x | y << 16, 0xFFFFFFFF = no pixel (tile edge)
     // queues

@@ -4,7 +4,10 @@
 //   k_wf_trace<closest>  persistent; lanes pull path ids from the extension queue, walk the BVH, store the hit
 //   k_wf_shade           consume the hit: miss / invalid material end the path; otherwise store the vertex and
 //                        enqueue one shadow segment per light with a non-zero contribution
-//   k_wf_trace<any hit>  persistent; shadow segments set a visibility bit per (path, light)
+//   k_wf_shadow_grid     shadow segments of lights that have a triangle-list grid (shadow_grid.h): look up the segment's cell as seen
+//                        from the light, test the cell's few triangles; sets a visibility bit per (path, light); what it cannot
+//                        decide cheaply goes on to
+//   k_wf_trace<any hit>  persistent; shadow segments walk the BVH and set the same visibility bits
 //   k_wf_finish          sum the visible contributions IN LIGHT ORDER, add emission, then terminal shading or
 //                        continuation sampling + russian roulette; survivors go to the next extension queue
 //   k_wf_advance         one thread: totals += queue sizes, swap queues, reset cursors
@@ -252,7 +255,7 @@ __global__ __launch_bounds__(WAVE, RT_WF8_MIN_WAVES) void k_wf_trace(DevScene sc
                     if (ANY) {
                         id = e & RT_WF_ID_MASK;
                         li = e >> 27;
-                        const V3 point = f4v(wb.vtx_p[id]), normal = f4v(wb.vtx_n[id]);
+                        const V3 point = f4v(wb.vtx[2 * (size_t)id]), normal = f4v(wb.vtx[2 * (size_t)id + 1]);
                         float dist;
                         shadow_segment(sc.lights[li], point, d, dist);
                         o = point + normal * EXT_EPS;
@@ -368,7 +371,7 @@ __global__ __launch_bounds__(WAVE, RT_WF8_MIN_WAVES) void k_wf_trace(DevScene sc
             const uint32_t busy = ((g_bits | t_bits) & 0xFFu) | (uint32_t)sp | (cur + 1u); // 0: nothing left to visit (and 0 on idle lanes)
             if (active && busy == 0u) { // segment finished
                 if (ANY) {
-                    if (hit.prim == RT_PRIM_MISS) atomicOr(reinterpret_cast<uint32_t*>(&wb.vtx_n[id]) + 3, 1u << li);
+                    if (hit.prim == RT_PRIM_MISS) atomicOr(reinterpret_cast<uint32_t*>(&wb.vtx[2 * (size_t)id + 1]) + 3, 1u << li);
                 } else {
                     const V3 hp = o + d * hit.t;
                     const uint32_t code = hit.prim == RT_PRIM_MISS ? RT_PRIM_MISS : ((hit.prim & RT_PRIM_SPHERE_FLAG) ? hit.prim : hit.slot);
@@ -465,7 +468,7 @@ __global__ __launch_bounds__(256, 8) void k_wf_shadow_grid(DevScene sc, rt::WfBu
         bool forward = false;
         if (e != WF_SENTINEL) {
             const uint32_t id = e & RT_WF_ID_MASK, li = e >> 27;
-            float4 vp = wb.vtx_p[id], vn = wb.vtx_n[id];
+            float4 vp = wb.vtx[2 * (size_t)id], vn = wb.vtx[2 * (size_t)id + 1];
             RT_KEEP4(vp);
             RT_KEEP4(vn);
             const V3 point = f4v(vp), normal = f4v(vn);
@@ -552,7 +555,7 @@ __global__ __launch_bounds__(256, 8) void k_wf_shadow_grid(DevScene sc, rt::WfBu
                                 if (cur < end) q0 = list[3 * (size_t)cur], q1 = list[3 * (size_t)cur + 1], q2 = list[3 * (size_t)cur + 2];
                             }
                         }
-                        if (visible) atomicOr(reinterpret_cast<uint32_t*>(&wb.vtx_n[id]) + 3, 1u << li);
+                        if (visible) atomicOr(reinterpret_cast<uint32_t*>(&wb.vtx[2 * (size_t)id + 1]) + 3, 1u << li);
                         if (COUNT && !forward) n_answered++;
                     }
                 }
@@ -634,12 +637,12 @@ __global__ __launch_bounds__(256, RT_WF_SHADE_WAVES) void k_wf_shade(DevScene sc
                 } else {
                     vertex = true;
                     m = load_material(sc, material_id);
-                    wb.vtx_p[id] = make_float4(point.x, point.y, point.z, __uint_as_float(material_id));
-                    wb.vtx_n[id] = make_float4(normal.x, normal.y, normal.z, 0.0f);
+                    wb.vtx[2 * (size_t)id] = make_float4(point.x, point.y, point.z, __uint_as_float(material_id));
+                    wb.vtx[2 * (size_t)id + 1] = make_float4(normal.x, normal.y, normal.z, 0.0f);
                 }
             }
         }
-        if (have && !vertex) wb.vtx_p[id] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu)); // "no vertex": k_wf_finish skips it
+        if (have && !vertex) wb.vtx[2 * (size_t)id] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu)); // "no vertex": k_wf_finish skips it
         if (shadows) {
             // which lights need a shadow segment (non-zero contribution)?  One bit per light, then ONE
             // aggregated append per wave: exclusive scan of the per-lane counts + a single atomicAdd.
@@ -712,8 +715,8 @@ __global__ __launch_bounds__(256, RT_WF_SHADE_WAVES) void k_wf_finish(DevScene s
         float4 vp = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
         float4 vn = vp, th = vp, ra = vp, rdin = vp;
         if (id != WF_SENTINEL) { // the whole path record in one round trip
-            vp = wb.vtx_p[id];
-            vn = wb.vtx_n[id];
+            vp = wb.vtx[2 * (size_t)id];
+            vn = wb.vtx[2 * (size_t)id + 1];
             th = wb.thr[id];
             ra = wb.rad[id];
             rdin = wb.ray_d[id];
