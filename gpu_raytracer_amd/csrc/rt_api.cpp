@@ -384,7 +384,7 @@ int upload_common(rt_ctx* ctx, const rt_sphere* spheres, uint32_t n_spheres, con
             size_t free_b = 0, total_b = 0;
             HIPCHK(ctx, hipMemGetInfo(&free_b, &total_b));
             rt::ShadowGridOptions lopt = gopt; // all grids together may take a quarter of what is free now
-            lopt.max_entries = std::min<uint64_t>(gopt.max_entries, free_b / 4 / n_lights / (RT_SG_ENTRY_QUADS * sizeof(uint4)));
+            lopt.max_entries = std::min<uint64_t>(gopt.max_entries, free_b / 4 / n_lights / (RT_SG_ENTRY_QUADS * sizeof(uint4))); // (+ 128 bytes per cell: at most 0.8 GB per light)
             for (uint32_t i = 0; i < n_lights; i++) {
                 rt::ShadowGridBuild gb;
                 const hipError_t e = rt::shadow_grid_build(d.tris, tree_tris, dl[i], box_lo, box_hi, lopt, d.stream, &gb);
@@ -393,8 +393,8 @@ int upload_common(rt_ctx* ctx, const rt_sphere* spheres, uint32_t n_spheres, con
                     gb = rt::ShadowGridBuild{};
                 }
                 hg[i] = gb.grid;
-                if (gb.cell_start) d.grid_allocs.push_back(gb.cell_start);
-                if (gb.entries) d.grid_allocs.push_back(gb.entries);
+                if (gb.blocks) d.grid_allocs.push_back(gb.blocks);
+                if (gb.overflow) d.grid_allocs.push_back(gb.overflow);
                 any = any || gb.grid.kind != RT_SG_KIND_NONE;
                 d.grid_info.push_back(gb);
             }
@@ -1154,7 +1154,7 @@ int rt_debug_shadow_grid(rt_ctx* ctx, uint32_t light, unsigned long long out[8])
             if (g.grid.kind == RT_SG_KIND_NONE) continue;
             out[0]++;
             out[1] += g.n_entries;
-            out[2] += g.n_entries * RT_SG_ENTRY_QUADS * sizeof(uint4) + ((size_t)g.grid.n_cells + 2) * 4;
+            out[2] += g.bytes;
         }
         out[3] = ctx->grid_diag[0];
         out[4] = ctx->grid_diag[1];

@@ -24,7 +24,7 @@
 
 #include "device_layout.h"
 
-struct DevShadowGrid { // one per light, 112 bytes
+struct DevShadowGrid { // one per light, 128 bytes
     uint32_t kind;     // 0: no grid (the BVH decides), 1: cube map about `origin`, 2: orthographic grid across axis_w
     uint32_t res;      // cells per side of a face
     uint32_t n_cells;  // faces * res * res; the pseudo-cell n_cells is the near list
@@ -38,19 +38,26 @@ struct DevShadowGrid { // one per light, 112 bytes
     float axis_w[3];   // kind 2: the direction TOWARD the light (DevLight::neg_ndir)
     float key_top;     // kind 2: a triangle's key is key_top - (largest coordinate along axis_w)
     float limit_margin; // a segment tests entries whose key is below (its own key + limit_margin)
-    uint32_t near_begin, near_end; // the near list's entries (= cell_start[n_cells], cell_start[n_cells + 1])
+    uint32_t near_begin, near_end; // the near list: entries [near_begin, near_end) of `overflow`
     uint32_t _pad;
-    const uint32_t* cell_start; // n_cells + 2: entries of cell c are [cell_start[c], cell_start[c + 1])
-    const uint4* entries;       // three per entry, 48 bytes: {key, v0.xyz} {e1.xyz, e2.x} {e2.yz, triangle record, 0} - the triangle travels with
-                                // its key (f32; kind 1: distance light - triangle, kind 2: see key_top), so a step of the walk is ONE gather:
-                                // random 48-byte records run at 44 G/s on MI355X, an 8-byte entry plus a record elsewhere at 24 G/s
-                                // (scripts/micro/random_read.hip)
+    // Cell c owns the 128-byte block blocks[8 c .. 8 c + 8) - ONE line of the L2, which is what a scattered read moves from HBM:
+    //   quad 0      {entries in the cell's list, where its 3rd and later entries start in `overflow`, key of the 3rd entry (+inf if none), 0}
+    //   quads 1-3   the list's first entry, quads 4-6 its second, quad 7 unused
+    // An entry is 48 bytes, {key, v0.xyz} {e1.xyz, e2.x} {e2.yz, triangle record, 0}: the triangle travels with its key (f32; kind 1:
+    // distance light - triangle, kind 2: see key_top).  Lists are sorted by key, a segment reads 2.2 entries on average (headline
+    // scene), so most segments are decided by their cell's one line; the stage is bound by HBM bandwidth (5.6 TB/s measured with
+    // separate offset and entry arrays, 335 bytes per segment), so lines per segment are what counts (scripts/micro/random_read.hip).
+    const uint4* blocks;
+    const uint4* overflow;
+    uint32_t _pad2[4];
 };
 
 #define RT_SG_KIND_NONE 0u
 #define RT_SG_KIND_CUBE 1u
 #define RT_SG_KIND_ORTHO 2u
 #define RT_SG_ENTRY_QUADS 3u
+#define RT_SG_BLOCK_QUADS 8u   /* 128 bytes per cell */
+#define RT_SG_BLOCK_ENTRIES 2u /* entries held in the cell's own block */
 
 namespace rt {
 
@@ -65,8 +72,9 @@ struct ShadowGridOptions {
 
 struct ShadowGridBuild {
     DevShadowGrid grid{};      // kind 0 when the light gets no grid (nothing allocated then)
-    void* cell_start = nullptr; // device allocations behind grid.cell_start / grid.entries, owned by the caller
-    void* entries = nullptr;
+    void* blocks = nullptr;    // device allocations behind grid.blocks / grid.overflow, owned by the caller
+    void* overflow = nullptr;
+    uint64_t bytes = 0;        // of the two
     uint64_t n_entries = 0;
     uint32_t near_count = 0;
     uint32_t longest = 0;      // longest cell list

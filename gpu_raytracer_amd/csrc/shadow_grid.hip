@@ -47,8 +47,9 @@ struct SgParams {
     float u0, v0, key_top;
     float margin_cells;  // rounding margin (>= SG_MARGIN_CELLS)
     uint32_t* cell_count; // count pass: entries per cell; fill pass: cursor per cell
-    const uint32_t* cell_start;
-    uint4* entries;
+    const uint32_t* ovf_start; // fill pass: where a list's entries beyond its block start in `overflow`
+    uint4* blocks;
+    uint4* overflow;
 };
 
 struct F3 {
@@ -106,10 +107,13 @@ __device__ __forceinline__ void sg_emit(const SgParams& p, uint32_t cell, const 
     if (!FILL) {
         atomicAdd(&p.cell_count[cell], 1u);
     } else {
-        const size_t pos = (size_t)(p.cell_start[cell] + atomicAdd(&p.cell_count[cell], 1u)) * RT_SG_ENTRY_QUADS;
-        p.entries[pos] = make_uint4(__float_as_uint(key), tri.q0.y, tri.q0.z, tri.q0.w);
-        p.entries[pos + 1] = tri.q1;
-        p.entries[pos + 2] = tri.q2;
+        const uint32_t k = atomicAdd(&p.cell_count[cell], 1u);
+        const uint32_t in_block = cell < p.n_cells ? RT_SG_BLOCK_ENTRIES : 0u; // (the near list lives in the overflow array only)
+        uint4* dst = k < in_block ? p.blocks + (size_t)cell * RT_SG_BLOCK_QUADS + 1u + RT_SG_ENTRY_QUADS * k
+                                  : p.overflow + (size_t)(p.ovf_start[cell] + (k - in_block)) * RT_SG_ENTRY_QUADS;
+        dst[0] = make_uint4(__float_as_uint(key), tri.q0.y, tri.q0.z, tri.q0.w);
+        dst[1] = tri.q1;
+        dst[2] = tri.q2;
     }
 }
 
@@ -283,39 +287,45 @@ __global__ __launch_bounds__(256) void k_sg_sum(const uint32_t* __restrict__ cou
     }
 }
 
-// cell_start[n + 1] = cell_start[n] + count[n] (the scan is exclusive); one thread
-__global__ void k_sg_total(uint32_t* cell_start, const uint32_t* count, uint32_t n) { cell_start[n + 1] = cell_start[n] + count[n]; }
-
-// Sorts every list of at most `heavy` entries by (key, record); statistics: [0] longest list, [1] cells over `heavy`
-__global__ __launch_bounds__(256) void k_sg_sort(const uint32_t* __restrict__ cell_start, uint4* __restrict__ entries, uint32_t n_lists, uint32_t heavy,
-                                                 uint32_t* __restrict__ stats) {
+// entries of each list that do not fit its block (the near list, index n_cells, has no block)
+__global__ __launch_bounds__(256) void k_sg_overflow(const uint32_t* __restrict__ count, uint32_t* __restrict__ ovf, uint32_t n_cells) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n_lists) return;
-    const uint32_t b = cell_start[c], e = cell_start[c + 1], n = e - b;
-    if (n == 0) return;
-    atomicMax(&stats[0], n);
-    if (n > heavy) {
-        atomicAdd(&stats[1], 1u);
-        return;
-    }
-    uint4* __restrict__ l = entries + (size_t)b * RT_SG_ENTRY_QUADS;
-    for (uint32_t i = 1; i < n; i++) {
-        const uint4 x0 = l[3 * i], x1 = l[3 * i + 1], x2 = l[3 * i + 2];
-        uint32_t j = i;
-        while (j > 0) {
-            const uint32_t yk = l[3 * (j - 1)].x, yr = l[3 * (j - 1) + 2].z;
-            if (yk < x0.x || (yk == x0.x && yr < x2.z)) break; // keys are non-negative floats: their bits order like the values
-            l[3 * j] = l[3 * (j - 1)];
-            l[3 * j + 1] = l[3 * (j - 1) + 1];
-            l[3 * j + 2] = l[3 * (j - 1) + 2];
-            j--;
+    if (c > n_cells) return;
+    const uint32_t n = count[c];
+    ovf[c] = c < n_cells ? (n > RT_SG_BLOCK_ENTRIES ? n - RT_SG_BLOCK_ENTRIES : 0u) : n;
+}
+// ovf_start[n + 1] = ovf_start[n] + ovf[n] (the scan is exclusive); one thread
+__global__ void k_sg_total(uint32_t* ovf_start, const uint32_t* ovf, uint32_t n) { ovf_start[n + 1] = ovf_start[n] + ovf[n]; }
+
+// Sorts every list of at most `heavy` entries by (key, record) and writes the cells' header quads; statistics: [0] longest list
+__global__ __launch_bounds__(256) void k_sg_sort(const uint32_t* __restrict__ count, const uint32_t* __restrict__ ovf_start, uint4* __restrict__ blocks,
+                                                 uint4* __restrict__ overflow, uint32_t n_cells, uint32_t heavy, uint32_t* __restrict__ stats) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > n_cells) return;
+    const uint32_t n = count[c], os = ovf_start[c];
+    const uint32_t in_block = c < n_cells ? RT_SG_BLOCK_ENTRIES : 0u;
+    uint4* __restrict__ blk = blocks + (size_t)c * RT_SG_BLOCK_QUADS; // (not touched for the near list)
+    auto at = [&](uint32_t i) -> uint4* { return i < in_block ? blk + 1u + RT_SG_ENTRY_QUADS * i : overflow + (size_t)(os + (i - in_block)) * RT_SG_ENTRY_QUADS; };
+    if (n) atomicMax(&stats[0], n);
+    if (n > 1 && n <= heavy) {
+        for (uint32_t i = 1; i < n; i++) {
+            const uint4 x0 = at(i)[0], x1 = at(i)[1], x2 = at(i)[2];
+            uint32_t j = i;
+            while (j > 0) {
+                const uint4* y = at(j - 1);
+                const uint32_t yk = y[0].x, yr = y[2].z;
+                if (yk < x0.x || (yk == x0.x && yr < x2.z)) break; // keys are non-negative floats: their bits order like the values
+                uint4* d = at(j);
+                d[0] = y[0], d[1] = y[1], d[2] = y[2];
+                j--;
+            }
+            if (j != i) {
+                uint4* d = at(j);
+                d[0] = x0, d[1] = x1, d[2] = x2;
+            }
         }
-        if (j != i) {
-            l[3 * j] = x0;
-            l[3 * j + 1] = x1;
-            l[3 * j + 2] = x2;
-        }
     }
+    if (c < n_cells) blk[0] = make_uint4(n, os, n > RT_SG_BLOCK_ENTRIES ? at(RT_SG_BLOCK_ENTRIES)[0].x : 0x7F800000u, 0u);
 }
 
 #define SG_CHK(call)                  \
@@ -407,21 +417,24 @@ hipError_t shadow_grid_build(const DevTri* d_tris, uint32_t n_records, const Dev
         limit_margin = (float)(2.0 * eps_eff + 1.0e-5 * d_max);
     }
 
-    uint32_t *count = nullptr, *cell_start = nullptr, *stats = nullptr;
+    uint32_t *count = nullptr, *ovf = nullptr, *ovf_start = nullptr, *stats = nullptr;
     unsigned long long* total64 = nullptr;
-    uint4* entries = nullptr;
+    uint4 *blocks = nullptr, *overflow = nullptr;
     void* temp = nullptr;
     auto cleanup = [&]() {
         (void)hipFree(count);
-        (void)hipFree(cell_start);
+        (void)hipFree(ovf);
+        (void)hipFree(ovf_start);
         (void)hipFree(stats);
         (void)hipFree(total64);
-        (void)hipFree(entries);
+        (void)hipFree(blocks);
+        (void)hipFree(overflow);
         (void)hipFree(temp);
     };
     const size_t lists = (size_t)p.n_cells + 1; // + the near list
     SG_CHK(hipMalloc((void**)&count, lists * 4));
-    SG_CHK(hipMalloc((void**)&cell_start, (lists + 1) * 4));
+    SG_CHK(hipMalloc((void**)&ovf, lists * 4));
+    SG_CHK(hipMalloc((void**)&ovf_start, (lists + 1) * 4));
     SG_CHK(hipMalloc((void**)&stats, 2 * 4));
     SG_CHK(hipMalloc((void**)&total64, 3 * 8));
     SG_CHK(hipMemsetAsync(total64, 0, 3 * 8, stream));
@@ -432,14 +445,15 @@ hipError_t shadow_grid_build(const DevTri* d_tris, uint32_t n_records, const Dev
     hipLaunchKernelGGL(k_sg_raster<false>, grid, block, 0, stream, p);
     SG_CHK(hipGetLastError());
     hipLaunchKernelGGL(k_sg_sum, dim3(1024), dim3(256), 0, stream, count, (uint32_t)lists, opt.heavy, total64);
+    hipLaunchKernelGGL(k_sg_overflow, dim3((uint32_t)((lists + 255) / 256)), dim3(256), 0, stream, count, ovf, p.n_cells);
     size_t temp_bytes = 0;
-    SG_CHK(rocprim::exclusive_scan(nullptr, temp_bytes, count, cell_start, 0u, lists, rocprim::plus<uint32_t>(), stream));
+    SG_CHK(rocprim::exclusive_scan(nullptr, temp_bytes, ovf, ovf_start, 0u, lists, rocprim::plus<uint32_t>(), stream));
     SG_CHK(hipMalloc(&temp, temp_bytes ? temp_bytes : 16));
-    SG_CHK(rocprim::exclusive_scan(temp, temp_bytes, count, cell_start, 0u, lists, rocprim::plus<uint32_t>(), stream));
-    hipLaunchKernelGGL(k_sg_total, dim3(1), dim3(1), 0, stream, cell_start, count, (uint32_t)(lists - 1));
-    uint32_t tail[2] = {0, 0}; // [start of the near list, total]
+    SG_CHK(rocprim::exclusive_scan(temp, temp_bytes, ovf, ovf_start, 0u, lists, rocprim::plus<uint32_t>(), stream));
+    hipLaunchKernelGGL(k_sg_total, dim3(1), dim3(1), 0, stream, ovf_start, ovf, (uint32_t)(lists - 1));
+    uint32_t tail[2] = {0, 0}; // [start of the near list, all overflow entries]
     unsigned long long sums[3] = {0, 0, 0};
-    SG_CHK(hipMemcpyAsync(tail, cell_start + lists - 1, 8, hipMemcpyDeviceToHost, stream));
+    SG_CHK(hipMemcpyAsync(tail, ovf_start + lists - 1, 8, hipMemcpyDeviceToHost, stream));
     SG_CHK(hipMemcpyAsync(sums, total64, 3 * 8, hipMemcpyDeviceToHost, stream));
     SG_CHK(hipStreamSynchronize(stream));
     const unsigned long long total = sums[0];
@@ -451,22 +465,29 @@ hipError_t shadow_grid_build(const DevTri* d_tris, uint32_t n_records, const Dev
     // cell in a thousand over `heavy`) against 11 node visits of the BVH; foliage-like clutter (bistro-like: 14 per cell, 4 % heavy, a
     // third of the segments handed on after walking a list for nothing) loses against the BVH, and such a light gets no grid.
     const bool long_lists = (double)total > opt.max_mean_list * (double)std::max<uint64_t>(1, sums[1]) || (double)sums[2] > opt.max_heavy_share * (double)sums[1];
+    // (total bounds the overflow entries, so the 32-bit scan above did not wrap when it is accepted here)
     if (total == 0 || total > std::min<uint64_t>(opt.max_entries, 0xFFFFFFFFull / RT_SG_ENTRY_QUADS) || near_count > opt.heavy || long_lists) {
         cleanup();
         return hipSuccess; // no grid for this light
     }
-    SG_CHK(hipMalloc((void**)&entries, (size_t)total * RT_SG_ENTRY_QUADS * sizeof(uint4)));
+    const size_t block_bytes = (size_t)p.n_cells * RT_SG_BLOCK_QUADS * sizeof(uint4), ovf_bytes = ((size_t)tail[1] + 1) * RT_SG_ENTRY_QUADS * sizeof(uint4);
+    SG_CHK(hipMalloc((void**)&blocks, block_bytes));
+    SG_CHK(hipMalloc((void**)&overflow, ovf_bytes));
+    SG_CHK(hipMemsetAsync(blocks, 0, block_bytes, stream)); // (an untouched cell is an empty list)
     SG_CHK(hipMemsetAsync(count, 0, lists * 4, stream));
-    p.cell_start = cell_start;
-    p.entries = entries;
+    p.ovf_start = ovf_start;
+    p.blocks = blocks;
+    p.overflow = overflow;
     hipLaunchKernelGGL(k_sg_raster<true>, grid, block, 0, stream, p);
     SG_CHK(hipGetLastError());
-    hipLaunchKernelGGL(k_sg_sort, dim3((uint32_t)((lists + 255) / 256)), dim3(256), 0, stream, cell_start, entries, (uint32_t)lists, opt.heavy, stats);
+    hipLaunchKernelGGL(k_sg_sort, dim3((uint32_t)((lists + 255) / 256)), dim3(256), 0, stream, count, ovf_start, blocks, overflow, p.n_cells, opt.heavy, stats);
     SG_CHK(hipGetLastError());
     uint32_t st[2] = {0, 0};
     SG_CHK(hipMemcpyAsync(st, stats, 8, hipMemcpyDeviceToHost, stream));
     SG_CHK(hipStreamSynchronize(stream));
     (void)hipFree(count);
+    (void)hipFree(ovf);
+    (void)hipFree(ovf_start);
     (void)hipFree(stats);
     (void)hipFree(total64);
     (void)hipFree(temp);
@@ -484,10 +505,11 @@ hipError_t shadow_grid_build(const DevTri* d_tris, uint32_t n_records, const Dev
     g.limit_margin = limit_margin;
     g.near_begin = tail[0];
     g.near_end = tail[1];
-    g.cell_start = cell_start;
-    g.entries = entries;
-    out->cell_start = cell_start;
-    out->entries = entries;
+    g.blocks = blocks;
+    g.overflow = overflow;
+    out->blocks = blocks;
+    out->overflow = overflow;
+    out->bytes = block_bytes + ovf_bytes;
     out->near_count = near_count;
     out->longest = st[0];
     return hipSuccess;

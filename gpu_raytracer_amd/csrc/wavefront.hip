@@ -507,41 +507,50 @@ __global__ __launch_bounds__(256, 8) void k_wf_shadow_grid(DevScene sc, rt::WfBu
                     forward = true;
                 }
                 if (!forward) {
-                    uint32_t cur = 0, end = 0;
+                    // the cell's block: header and the list's first two entries in one 128-byte line
+                    const uint4 none = make_uint4(0x7F800000u, 0u, 0u, 0u); // key +inf
+                    uint4 hd = make_uint4(0u, 0u, 0x7F800000u, 0u), q0 = none, q1 = none, q2 = none;
+                    const uint4* __restrict__ blk = g.blocks + (size_t)(cell == 0xFFFFFFFFu ? 0u : cell) * RT_SG_BLOCK_QUADS;
                     if (cell != 0xFFFFFFFFu) {
-                        cur = g.cell_start[cell];
-                        end = g.cell_start[cell + 1];
+                        hd = blk[0];
+                        q0 = blk[1], q1 = blk[2], q2 = blk[3];
+                        RT_KEEP4(hd);
+                        RT_KEEP4(q0);
+                        RT_KEEP4(q1);
+                        RT_KEEP4(q2);
                     }
-                    if (end - cur > g.heavy) {
+                    const uint32_t count = hd.x;
+                    if (count > g.heavy) {
                         forward = true;
                     } else {
-                        const uint4* __restrict__ list = g.entries; // 48-byte entries: {key, v0} {e1, e2.x} {e2.yz, record, 0}
+                        const uint4* __restrict__ ovf = g.overflow; // 48-byte entries: {key, v0} {e1, e2.x} {e2.yz, record, 0}
                         // triangles too close to the light for a bounded dilation: tested by every segment of the light (normally none)
                         bool occluded = false;
                         for (uint32_t k = g.near_begin; k < g.near_end && !occluded; k++) {
-                            const uint4 q0 = list[3 * (size_t)k], q1 = list[3 * (size_t)k + 1], q2 = list[3 * (size_t)k + 2];
+                            const uint4 n0 = ovf[3 * (size_t)k], n1 = ovf[3 * (size_t)k + 1], n2 = ovf[3 * (size_t)k + 2];
                             if (COUNT) n_tests++;
                             float t;
-                            occluded = moller_trumbore(v3(__uint_as_float(q0.y), __uint_as_float(q0.z), __uint_as_float(q0.w)),
-                                                       v3(__uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z)),
-                                                       v3(__uint_as_float(q1.w), __uint_as_float(q2.x), __uint_as_float(q2.y)), o, d, t) &&
+                            occluded = moller_trumbore(v3(__uint_as_float(n0.y), __uint_as_float(n0.z), __uint_as_float(n0.w)),
+                                                       v3(__uint_as_float(n1.x), __uint_as_float(n1.y), __uint_as_float(n1.z)),
+                                                       v3(__uint_as_float(n1.w), __uint_as_float(n2.x), __uint_as_float(n2.y)), o, d, t) &&
                                        t > RT_MIN_RAY_DISTANCE && t < dist;
                         }
                         bool visible = false;
                         if (!occluded) {
-                            const uint4 none = make_uint4(0x7F800000u, 0u, 0u, 0u); // key +inf
-                            uint4 q0 = none, q1 = none, q2 = none;
-                            if (cur < end) q0 = list[3 * (size_t)cur], q1 = list[3 * (size_t)cur + 1], q2 = list[3 * (size_t)cur + 2];
-                            for (uint32_t n = 0;; n++) {
-                                if (cur >= end || !(__uint_as_float(q0.x) < limit)) { // every later triangle lies beyond the segment's end
+                            if (count == 0u) q0 = none;
+                            for (uint32_t i = 0;; i++) { // entry i is in q0..q2 (its key only, from the header, when i == 2 comes up)
+                                if (i >= count || !(__uint_as_float(q0.x) < limit)) { // every later triangle lies beyond the segment's end
                                     visible = true;
                                     break;
                                 }
-                                if (n == RT_WF_GRID_WALK) {
+                                if (i == RT_WF_GRID_WALK) {
                                     forward = true;
                                     break;
                                 }
-                                cur++;
+                                if (i == RT_SG_BLOCK_ENTRIES) { // the first entry beyond the block is fetched only now that its key (header) says it is needed
+                                    const size_t at = 3 * (size_t)hd.y;
+                                    q0 = ovf[at], q1 = ovf[at + 1], q2 = ovf[at + 2];
+                                }
                                 if (COUNT) n_entries++, n_tests++;
                                 float t;
                                 // the acceptance of test_triangle for a segment that has hit nothing yet: 1e-5 < t < its length
@@ -550,9 +559,18 @@ __global__ __launch_bounds__(256, 8) void k_wf_shadow_grid(DevScene sc, rt::WfBu
                                                     v3(__uint_as_float(q1.w), __uint_as_float(q2.x), __uint_as_float(q2.y)), o, d, t) &&
                                     t > RT_MIN_RAY_DISTANCE && t < dist)
                                     break; // occluded
-                                // (fetching the next entry ahead of the test was measured: 4 % slower - a third of the fetches are for nothing)
+                                // the next entry: the second of the block (same line); of the third only the key (it is in the header); later
+                                // ones whole (they follow the third in the overflow array)
+                                const uint32_t nx = i + 1u;
                                 q0 = none;
-                                if (cur < end) q0 = list[3 * (size_t)cur], q1 = list[3 * (size_t)cur + 1], q2 = list[3 * (size_t)cur + 2];
+                                if (nx < count) {
+                                    if (nx < RT_SG_BLOCK_ENTRIES) q0 = blk[4], q1 = blk[5], q2 = blk[6];
+                                    else if (nx == RT_SG_BLOCK_ENTRIES) q0.x = hd.z;
+                                    else {
+                                        const size_t at = 3 * (size_t)(hd.y + (nx - RT_SG_BLOCK_ENTRIES));
+                                        q0 = ovf[at], q1 = ovf[at + 1], q2 = ovf[at + 2];
+                                    }
+                                }
                             }
                         }
                         if (visible) atomicOr(reinterpret_cast<uint32_t*>(&wb.vtx[2 * (size_t)id + 1]) + 3, 1u << li);
