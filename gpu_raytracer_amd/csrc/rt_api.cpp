@@ -34,7 +34,9 @@ thread_local std::string g_create_error;
 struct DeviceState {
     int device = -1;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr; // the second lane of the wavefront pipeline (batches alternate between the two)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_start = nullptr, ev_join = nullptr, ev_res[2] = {nullptr, nullptr};
     DevNode8* nodes = nullptr;
     DevTri* tris = nullptr;
     DevSphere* spheres = nullptr;
@@ -54,7 +56,10 @@ struct DeviceState {
     std::vector<void*> grid_allocs;
     std::vector<rt::ShadowGridBuild> grid_info;
     rt::WfBuffers wf{};                                    // wavefront pipeline state (extended mode)
+    rt::WfBuffers wf2{};                                   // ... of the second lane (its own path state, queues and counters; the pixel sums are shared)
+    std::vector<void*> wf2_allocs;
     bool used_wavefront = false;
+    bool used_two_lanes = false;
     uint32_t wf_lights = 0;
     uint32_t wf_spp = 0; // spp the current wavefront allocation was sized for
     std::vector<void*> wf_allocs;
@@ -91,6 +96,10 @@ struct rt_ctx {
 };
 
 namespace {
+
+#ifndef RT_WF_LANES_DEFAULT
+#define RT_WF_LANES_DEFAULT 2 /* measured on the headline frame: 179.7 - 188.1 ms against 197.6 - 199.0 with one lane; 16 spp: 48.8 against 51.9 */
+#endif
 
 #define HIPCHK(ctx, call)                                                                                       \
     do {                                                                                                        \
@@ -130,6 +139,9 @@ void free_wavefront(DeviceState& d) {
     (void)hipSetDevice(d.device);
     for (void* p : d.wf_allocs) (void)hipFree(p);
     d.wf_allocs.clear();
+    for (void* p : d.wf2_allocs) (void)hipFree(p);
+    d.wf2_allocs.clear();
+    d.wf2 = rt::WfBuffers{};
     d.wf = rt::WfBuffers{};
     d.wf_lights = 0;
 }
@@ -444,21 +456,23 @@ int upload_common(rt_ctx* ctx, const rt_sphere* spheres, uint32_t n_spheres, con
 }
 
 // Path-state arrays and queues of the wavefront pipeline, sized for `batch` samples per owned pixel block.
-int ensure_wavefront(rt_ctx* ctx, DeviceState& d, uint32_t n_blocks, uint32_t batch, uint32_t n_lights) {
+int ensure_wavefront(rt_ctx* ctx, DeviceState& d, uint32_t n_blocks, uint32_t batch, uint32_t n_lights, bool two_lanes) {
     const uint32_t capacity = n_blocks * batch * 64u;
     // overflow entries (64-bit) per lane beyond the LDS part of the stack
     const uint32_t ovf_entries = ctx->scene_counts.stack_entries + 2u > RT_WF8_LDS_STACK ? ctx->scene_counts.stack_entries + 2u - RT_WF8_LDS_STACK : 1u;
     if (d.wf.capacity >= capacity && d.wf.n_blocks == n_blocks && d.wf.batch == batch && d.wf_lights >= n_lights && d.wf.counters &&
-        d.wf.ovf_entries >= ovf_entries)
+        d.wf.ovf_entries >= ovf_entries && (!two_lanes || d.wf2.counters))
         return RT_OK;
     free_wavefront(d);
     HIPCHK(ctx, hipSetDevice(d.device));
+    for (int lane = 0; lane < (two_lanes ? 2 : 1); lane++) {
+    std::vector<void*>& owned = lane ? d.wf2_allocs : d.wf_allocs;
     auto alloc = [&](void** p, size_t bytes) -> hipError_t {
         hipError_t e = hipMalloc(p, bytes ? bytes : 16);
-        if (e == hipSuccess) d.wf_allocs.push_back(*p);
+        if (e == hipSuccess) owned.push_back(*p);
         return e;
     };
-    rt::WfBuffers& w = d.wf;
+    rt::WfBuffers& w = lane ? d.wf2 : d.wf;
     const size_t P = capacity ? capacity : 64;
     HIPCHK(ctx, alloc((void**)&w.ray_o, P * 16));
     HIPCHK(ctx, alloc((void**)&w.ray_d, P * 16));
@@ -481,12 +495,14 @@ int ensure_wavefront(rt_ctx* ctx, DeviceState& d, uint32_t n_blocks, uint32_t ba
     w.q_shadow_cap = (uint32_t)shadow_slots;
     HIPCHK(ctx, alloc((void**)&w.counters, rt::WF_N_COUNTERS * sizeof(uint32_t)));
     HIPCHK(ctx, alloc((void**)&w.totals, 16 * sizeof(unsigned long long)));
-    HIPCHK(ctx, alloc((void**)&w.accum, (size_t)std::max(1u, n_blocks) * 64 * 16));
+    if (lane == 0) HIPCHK(ctx, alloc((void**)&w.accum, (size_t)std::max(1u, n_blocks) * 64 * 16));
+    else w.accum = d.wf.accum; // one running sum per pixel: the lanes' resolves are ordered by events
     HIPCHK(ctx, alloc((void**)&w.stack_ovf, (size_t)rt::wf_persistent_waves() * ovf_entries * 64 * 8));
     w.ovf_entries = ovf_entries;
     w.n_blocks = n_blocks;
     w.batch = batch;
     w.capacity = capacity;
+    }
     d.wf_lights = n_lights;
     return RT_OK;
 }
@@ -504,7 +520,7 @@ uint64_t wavefront_max_paths(uint32_t n_lights) {
     return std::min<uint64_t>((uint64_t)RT_WF_ID_MASK + 1, (1ull << 29) / lights);
 }
 
-uint32_t wavefront_batch(uint32_t n_blocks, uint32_t spp, uint32_t n_lights, size_t free_bytes) {
+uint32_t wavefront_batch(uint32_t n_blocks, uint32_t spp, uint32_t n_lights, size_t free_bytes, bool two_lanes) {
     const uint64_t per_sample = std::max<uint64_t>(1, (uint64_t)n_blocks * 64u);
     const uint64_t hard_limit = std::max<uint64_t>(1, wavefront_max_paths(n_lights) / per_sample); // samples per batch the ids allow
     if (const char* e = std::getenv("RT_WF_BATCH")) {
@@ -517,7 +533,8 @@ uint32_t wavefront_batch(uint32_t n_blocks, uint32_t spp, uint32_t n_lights, siz
     const uint64_t bytes_per_path = 8 * 16 + 4 + 2 * 16 + 16 * lights; // path state, vis, pxy, two extension queues, shadow queue (4 slots per entry)
     target_paths = std::min<uint64_t>(target_paths, free_bytes / 2 / bytes_per_path);
     target_paths = std::min<uint64_t>(target_paths, wavefront_max_paths(n_lights));
-    const uint32_t max_batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(spp, target_paths / per_sample));
+    uint32_t max_batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(spp, target_paths / per_sample));
+    if (two_lanes && spp >= 2) max_batch = std::min(max_batch, (spp + 1) / 2); // two lanes want two batches, also of a frame that would fit one
     const uint32_t n_batches = (spp + max_batch - 1) / max_batch;
     return std::max(1u, (spp + n_batches - 1) / std::max(1u, n_batches));
 }
@@ -575,29 +592,52 @@ int run_frame(rt_ctx* ctx, DevFrame fr, bool counters, uint32_t world, uint32_t 
             const uint32_t n_blocks = f.n_owned_tiles * rt::blocks_per_tile(f.tile_size);
             size_t free_b = 0, total_b = 0;
             HIPCHK(ctx, hipMemGetInfo(&free_b, &total_b));
-            const uint32_t batch = d.wf.n_blocks == n_blocks && d.wf_spp == f.spp && d.wf.batch && d.wf_lights >= ctx->scene_counts.n_lights ? d.wf.batch // same frame shape as last time: keep the allocation
-                                                                                               : wavefront_batch(n_blocks, f.spp, ctx->scene_counts.n_lights, free_b);
+            const char* lanes_env = std::getenv("RT_WF_LANES"); // (read per frame: tests and A/B runs switch it)
+            const bool two_lanes_on = lanes_env ? std::atoi(lanes_env) >= 2 : RT_WF_LANES_DEFAULT >= 2;
+            const uint32_t batch = d.wf.n_blocks == n_blocks && d.wf_spp == f.spp && d.wf.batch && d.wf_lights >= ctx->scene_counts.n_lights && d.used_two_lanes == (two_lanes_on && f.spp >= 2) ? d.wf.batch // same frame shape as last time: keep the allocation
+                                                                                               : wavefront_batch(n_blocks, f.spp, ctx->scene_counts.n_lights, two_lanes_on ? free_b / 2 : free_b, two_lanes_on);
             d.wf_spp = f.spp;
-            rc = ensure_wavefront(ctx, d, n_blocks, batch, ctx->scene_counts.n_lights);
+            // Two lanes (RT_WF_LANES=2, the default when a frame has two or more batches): batches alternate between two streams with their own
+            // path state, so that one batch's shadow stage (bound by HBM bandwidth since the light grids) runs beside the other's closest-hit
+            // traversal (bound by VALU issue).  The pixel sums are added in batch order: a resolve waits for the previous batch's.
+            const uint32_t n_batches = (f.spp + batch - 1) / batch;
+            const bool two = two_lanes_on && n_batches >= 2 && d.stream2;
+            rc = ensure_wavefront(ctx, d, n_blocks, batch, ctx->scene_counts.n_lights, two);
             if (rc != RT_OK) return rc;
             HIPCHK(ctx, hipMemsetAsync(d.wf.totals, 0, 16 * sizeof(unsigned long long), d.stream));
             HIPCHK(ctx, hipEventRecord(d.ev0, d.stream)); // re-record: allocation above is not part of the kernel time
+            if (two) {
+                HIPCHK(ctx, hipEventRecord(d.ev_start, d.stream));
+                HIPCHK(ctx, hipStreamWaitEvent(d.stream2, d.ev_start, 0));
+                HIPCHK(ctx, hipMemsetAsync(d.wf2.totals, 0, 16 * sizeof(unsigned long long), d.stream2));
+            }
             const DevScene dsc = scene_for(ctx, d);
-            d.wf.grids = (f.flags & RT_FLAG_NO_SHADOW_GRID) ? nullptr : d.grids;
-            for (uint32_t first = 0; first < f.spp; first += batch) {
+            d.wf.grids = d.wf2.grids = (f.flags & RT_FLAG_NO_SHADOW_GRID) ? nullptr : d.grids;
+            uint32_t j = 0;
+            for (uint32_t first = 0; first < f.spp; first += batch, j++) {
                 const uint32_t n = std::min(batch, f.spp - first);
-                HIPCHK(ctx, rt::wf_generate(dsc, f, d.wf, first, n, d.stream));
+                const uint32_t lane = two ? (j & 1u) : 0u;
+                rt::WfBuffers& w = lane ? d.wf2 : d.wf;
+                hipStream_t st = lane ? d.stream2 : d.stream;
+                HIPCHK(ctx, rt::wf_generate(dsc, f, w, first, n, st));
                 for (uint32_t it = 0; it <= f.max_bounce; it++) {
-                    HIPCHK(ctx, rt::wf_bounce(dsc, f, d.wf, it, counters, d.stream));
+                    HIPCHK(ctx, rt::wf_bounce(dsc, f, w, it, counters, st));
                     if ((it & 7u) == 7u && it < f.max_bounce) { // long paths: stop as soon as every path has ended
                         uint32_t alive = 0;
-                        HIPCHK(ctx, hipMemcpyAsync(&alive, d.wf.counters + rt::WF_EXT_COUNT, 4, hipMemcpyDeviceToHost, d.stream));
-                        HIPCHK(ctx, hipStreamSynchronize(d.stream));
+                        HIPCHK(ctx, hipMemcpyAsync(&alive, w.counters + rt::WF_EXT_COUNT, 4, hipMemcpyDeviceToHost, st));
+                        HIPCHK(ctx, hipStreamSynchronize(st));
                         if (alive == 0) break;
                     }
                 }
-                HIPCHK(ctx, rt::wf_resolve(f, d.wf, targets_for(d), n, first == 0, first + n >= f.spp, d.stream));
+                if (two && j > 0) HIPCHK(ctx, hipStreamWaitEvent(st, d.ev_res[(j - 1u) & 1u], 0));
+                HIPCHK(ctx, rt::wf_resolve(f, w, targets_for(d), n, first == 0, first + n >= f.spp, st));
+                if (two) HIPCHK(ctx, hipEventRecord(d.ev_res[j & 1u], st));
             }
+            if (two) { // the frame ends when both lanes have
+                HIPCHK(ctx, hipEventRecord(d.ev_join, d.stream2));
+                HIPCHK(ctx, hipStreamWaitEvent(d.stream, d.ev_join, 0));
+            }
+            d.used_two_lanes = two;
             d.used_wavefront = true;
         } else if (f.mode == RT_MODE_EXTENDED) {
             d.used_wavefront = false;
@@ -632,6 +672,11 @@ int run_frame(rt_ctx* ctx, DevFrame fr, bool counters, uint32_t world, uint32_t 
         if (extended && d.used_wavefront) {
             unsigned long long t[16];
             HIPCHK(ctx, hipMemcpy(t, d.wf.totals, sizeof t, hipMemcpyDeviceToHost));
+            if (d.used_two_lanes) {
+                unsigned long long t2[16];
+                HIPCHK(ctx, hipMemcpy(t2, d.wf2.totals, sizeof t2, hipMemcpyDeviceToHost));
+                for (int k = 0; k < 16; k++) t[k] = k == 5 ? std::max(t[k], t2[k]) : t[k] + t2[k]; // ([5] is a high-water mark)
+            }
             cnt[0] += t[0] + t[1] + t[2];
             cnt[3] += t[0];
             cnt[4] += t[1];
@@ -752,7 +797,9 @@ int rt_create(rt_ctx** out, const int* device_ids, int n_devices) {
             rt_destroy(ctx);
             return RT_ERR_BAD_ARG;
         }
-        if ((e = hipSetDevice(d.device)) != hipSuccess || (e = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking)) != hipSuccess ||
+        if ((e = hipSetDevice(d.device)) != hipSuccess || (e = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking)) != hipSuccess || (e = hipStreamCreateWithFlags(&d.stream2, hipStreamNonBlocking)) != hipSuccess ||
+            (e = hipEventCreateWithFlags(&d.ev_start, hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&d.ev_join, hipEventDisableTiming)) != hipSuccess ||
+            (e = hipEventCreateWithFlags(&d.ev_res[0], hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&d.ev_res[1], hipEventDisableTiming)) != hipSuccess ||
             (e = hipEventCreate(&d.ev0)) != hipSuccess || (e = hipEventCreate(&d.ev1)) != hipSuccess ||
             (e = hipMalloc((void**)&d.counters, 16 * sizeof(unsigned long long))) != hipSuccess) {
             g_create_error = std::string("rt_create: ") + hipGetErrorString(e);
@@ -778,6 +825,9 @@ void rt_destroy(rt_ctx* ctx) {
         (void)hipFree(d.counters);
         if (d.ev0) (void)hipEventDestroy(d.ev0);
         if (d.ev1) (void)hipEventDestroy(d.ev1);
+        for (hipEvent_t e : {d.ev_start, d.ev_join, d.ev_res[0], d.ev_res[1]})
+            if (e) (void)hipEventDestroy(e);
+        if (d.stream2) (void)hipStreamDestroy(d.stream2);
         if (d.stream) (void)hipStreamDestroy(d.stream);
     }
     delete ctx;

@@ -142,3 +142,25 @@ def test_full_size_frames_agree(gpu_ctx):
     sc = scenes.sponza_like()
     info, use, st = _same_frame(gpu_ctx, sc, 1920, 1080, 4, 4, expect_grids=len(sc.lights))
     assert use["segments_answered"] > 0.95 * st["shadow_rays"]
+
+
+def test_one_lane_and_two_lanes_give_the_same_frame(gpu_ctx):
+    """The pipeline runs its batches alternately on two streams (default) or all on one (RT_WF_LANES=1): same pixel sums, added in the
+    same order."""
+    sc = scenes.sponza_like()
+    gpu_ctx.upload_scene(sc)
+    frames = {}
+    for lanes in ("2", "1", "2"):
+        os.environ["RT_WF_LANES"] = lanes
+        try:
+            for spp in (1, 2, 5):
+                st = gpu_ctx.render(480, 270, sc.camera, mode=2, spp=spp, max_bounces=4, frame_seed=3)
+                img = gpu_ctx.read_rgb32f().copy()
+                key = (spp,)
+                if key in frames:
+                    np.testing.assert_array_equal(frames[key][0].view(np.uint32), img.view(np.uint32), err_msg=f"lanes {lanes} spp {spp}")
+                    assert frames[key][1] == (st["rays"], st["shadow_rays"])
+                else:
+                    frames[key] = (img, (st["rays"], st["shadow_rays"]))
+        finally:
+            del os.environ["RT_WF_LANES"]
