@@ -593,7 +593,9 @@ int run_frame(rt_ctx* ctx, DevFrame fr, bool counters, uint32_t world, uint32_t 
             size_t free_b = 0, total_b = 0;
             HIPCHK(ctx, hipMemGetInfo(&free_b, &total_b));
             const char* lanes_env = std::getenv("RT_WF_LANES"); // (read per frame: tests and A/B runs switch it)
-            const bool two_lanes_on = lanes_env ? std::atoi(lanes_env) >= 2 : RT_WF_LANES_DEFAULT >= 2;
+            // by default only for frames whose shadow stage runs on light grids: with the BVH walk both big stages are VALU-bound and sharing
+            // the chip gains nothing (bistro-like 4K share: 136.7 ms on two lanes against 127.3 on one)
+            const bool two_lanes_on = lanes_env ? std::atoi(lanes_env) >= 2 : (RT_WF_LANES_DEFAULT >= 2 && d.grids != nullptr && !(f.flags & RT_FLAG_NO_SHADOW_GRID));
             const uint32_t batch = d.wf.n_blocks == n_blocks && d.wf_spp == f.spp && d.wf.batch && d.wf_lights >= ctx->scene_counts.n_lights && d.used_two_lanes == (two_lanes_on && f.spp >= 2) ? d.wf.batch // same frame shape as last time: keep the allocation
                                                                                                : wavefront_batch(n_blocks, f.spp, ctx->scene_counts.n_lights, two_lanes_on ? free_b / 2 : free_b, two_lanes_on);
             d.wf_spp = f.spp;
