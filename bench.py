@@ -325,6 +325,16 @@ def main():
     gather_ms = max_over_ranks(dist, (time.perf_counter() - g0) * 1e3, dev)
 
     # exact node / triangle fetch counts and wave-level step statistics from the counting variant of the same kernels
+    # the same frame on one lane (RT_WF_LANES=1: every stage kernel alone on the chip) - what the rocprofv3 summaries under profiles/ time
+    one_lane_ms = None
+    if mode_name == "extended" and os.environ.get("RT_WF_LANES") is None:
+        os.environ["RT_WF_LANES"] = "1"
+        try:
+            step()
+            one_lane_ms = float(np.mean([step()["kernel_ms"] for _ in range(2)]))
+        finally:
+            del os.environ["RT_WF_LANES"]
+        step()
     stc = step(counters=True)
     diag = list(ctx.debug_counters().values())
     grid = ctx.debug_shadow_grid()  # the per-light triangle lists of the shadow stage (csrc/shadow_grid.h): what they hold and answered
@@ -361,6 +371,7 @@ def main():
             "kernel": "k_render_reference" if mode_name == "reference" else
                       "wavefront pipeline, all stage kernels of one frame (k_wf_shadow_grid + k_wf_trace<shadow> + k_wf_trace<closest> + k_wf_shade + k_wf_finish + k_wf_generate + k_wf_resolve)",
             "kernel_avg_ms": avg_kernel_ms,
+            "kernel_avg_ms_one_lane": one_lane_ms,
             "compulsory_hbm_bytes_per_launch": compulsory_bytes,
             "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_GBps": alg_bytes / (avg_kernel_ms * 1e-3) / 1e9,
             "state_bytes_per_segment": {"extension": S_STATE_EXTENSION, "shadow": S_STATE_SHADOW, "path": S_STATE_PATH} if wavefront else None,
@@ -370,7 +381,9 @@ def main():
             "shadow_grids": {"lights_with_grid": grid["lights_with_grid"], "bytes": grid["bytes"], "entries": grid["entries"],
                              "shadow_segments_answered_share": grid["segments_answered"] / max(stc["shadow_rays"], 1),
                              "entries_read_per_answered_segment": grid["entries_read"] / max(grid["segments_answered"], 1)} if wavefront else None,
-            "note": "launch = one frame on rank 0 (all stage kernels, HIP events on the launch stream).  achieved/frac: HBM-side bytes "
+            "note": "launch = one frame on rank 0 (all stage kernels, HIP events on the launch stream; with light grids the batches run on two "
+                    "streams and their kernels overlap: kernel_avg_ms_one_lane is the same frame with RT_WF_LANES=1, which is what the per-kernel "
+                    "rocprofv3 summaries under profiles/ add up to).  achieved/frac: HBM-side bytes "
                     "from the committed PMC passes of this very build (FETCH_SIZE is uncalibrated for 16-byte gathers, "
                     "MI355X_MICROARCH.md).  algorithmic_*: SURVEY 8d's per-segment figure (node fetches x 80 B + triangle fetches x "
                     "48 B + per-kind path state + pixels x 36 B); ~90 % of it is served by L1/L2, so it is a rate, not an HBM fraction",

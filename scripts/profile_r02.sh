@@ -9,6 +9,9 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
+# one lane: on two lanes (the default with light grids) the other lane's kernels run beside the one being timed and every duration in
+# the trace includes the waiting for them; bench.py reports the one-lane frame time next to the two-lane one for the comparison
+export RT_WF_LANES=${RT_WF_LANES:-1}
 cd /tmp
 ARGS="--no-cpu-baseline $@"
 T="timeout -k 10 ${PROFILE_TIMEOUT:-300}"
