@@ -58,6 +58,7 @@ struct DevShadowGrid { // one per light, 128 bytes
 #define RT_SG_ENTRY_QUADS 3u
 #define RT_SG_BLOCK_QUADS 8u   /* 128 bytes per cell */
 #define RT_SG_BLOCK_ENTRIES 2u /* entries held in the cell's own block */
+#define RT_SG_SORTED_PREFIX 16u /* a list's first 16 entries are its 16 nearest in order; later ones follow unordered (a walk gives up before them) */
 
 namespace rt {
 
