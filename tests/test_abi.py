@@ -69,3 +69,21 @@ def test_null_context_calls_return_bad_arg(rt_api):
     h = C.c_void_p(0)
     assert lib.rt_create(C.byref(h), null, C.c_int(0)) == -1
     lib.rt_destroy(null)  # no-op
+
+
+def test_python_flag_values_are_the_headers(rt_api):
+    """gpu_raytracer_amd/api.py restates the RT_FLAG_* / RT_MODE_* constants of include/rt_hip.h: they must agree (a flag that drifts
+    silently selects another code path), and the debug entry points the tests and bench.py call must be exported."""
+    import re
+    header = open(os.path.join(ROOT, "include", "rt_hip.h")).read()
+    defines = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+(RT_(?:FLAG|MODE)_[A-Z0-9_]+)\s+(\d+)u", header)}
+    assert defines["RT_FLAG_NO_SHADOW_GRID"] == 16
+    for name, value in defines.items():
+        py = name[3:]  # RT_FLAG_X -> FLAG_X
+        if hasattr(rt_api, py):
+            assert getattr(rt_api, py) == value, name
+    for flag in ("FLAG_COUNTERS", "FLAG_NO_SHADOWS", "FLAG_KERNEL_V1", "FLAG_KERNEL_SM", "FLAG_NO_SHADOW_GRID"):
+        assert "RT_" + flag in defines and hasattr(rt_api, flag), flag
+    lib = rt_api.load()
+    for sym in ("rt_debug_shadow_grid", "rt_debug_counters", "rt_debug_check_bvh"):
+        assert hasattr(lib, sym), sym
