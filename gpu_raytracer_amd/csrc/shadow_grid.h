@@ -52,6 +52,9 @@ struct DevShadowGrid { // one per light, 128 bytes
     uint32_t _pad2[4];
 };
 
+static_assert(sizeof(DevShadowGrid) == 128, "DevShadowGrid is staged in LDS and uploaded as an array");
+
+#define RT_SG_EXT_EPS 0.001f /* the origin offset of a shadow segment the lists' dilation is derived from: device_common.h EXT_EPS (checked in wavefront.hip) */
 #define RT_SG_KIND_NONE 0u
 #define RT_SG_KIND_CUBE 1u
 #define RT_SG_KIND_ORTHO 2u

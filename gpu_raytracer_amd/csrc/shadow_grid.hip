@@ -16,7 +16,7 @@
 //    the clip / projection arithmetic here (relative 1e-6), and the triangle test's tolerance (it accepts rays that pass
 //    a triangle's edge by ~1e-7 of the coordinates' magnitude): all of these are below a hundredth of a cell for any
 //    scene whose grid is enabled (shadow_grid_build refuses scenes whose coordinates are too large for that);
-//  * keys: a triangle is skipped by segments that end before its nearest point (point lights: key = r_min shrunk by 1e-4,
+//  * keys: a triangle is skipped by segments that end before its nearest point (point lights: key = r_min shrunk by 1e-4 and 1e-5 of its extent,
 //    the segment's limit is its length + 2 eps_eff + slack; directional: the coordinate along the light's direction).
 #include "shadow_grid.h"
 
@@ -32,7 +32,7 @@
 
 namespace {
 
-#define SG_EXT_EPS 0.001f /* device_common.h EXT_EPS: the origin offset of a shadow segment */
+#define SG_EXT_EPS RT_SG_EXT_EPS
 #define SG_MARGIN_CELLS 0.5f
 #define SG_MAX_CONE_CELLS 8.0f
 
@@ -223,7 +223,12 @@ __global__ __launch_bounds__(256) void k_sg_raster(SgParams p) {
     }
     const F3 L = f3(p.L[0], p.L[1], p.L[2]);
     const F3 q0 = v0 - L, q1 = v1 - L, q2 = v2 - L;
-    const float r_min = sqrtf(fmaxf(sg_origin_tri_dist2(q0, q1, q2), 0.0f)) * (1.0f - 1.0e-4f);
+    // the nearest point's distance, shrunk: by 1e-4 of itself and by 1e-5 of the triangle's extent - on a sliver the closest-point
+    // arithmetic places the point inexactly ALONG the triangle, which moves its distance in the second order only; a key may be
+    // too small (the triangle is then tested by a few segments more) but never larger than the true distance
+    const F3 ea = v1 - v0, eb = v2 - v0;
+    const float extent = sqrtf(dot3(ea, ea)) + sqrtf(dot3(eb, eb));
+    const float r_min = fmaxf(sqrtf(fmaxf(sg_origin_tri_dist2(q0, q1, q2), 0.0f)) * (1.0f - 1.0e-4f) - 1.0e-5f * extent, 0.0f);
     const float cone_cells = r_min > 0.0f ? 3.5f * (p.eps_eff / r_min) * p.scale : 3.0e38f;
     if (!(cone_cells <= SG_MAX_CONE_CELLS)) { // too close to the light for a bounded dilation: every segment of the light tests it
         if (lane == 0) sg_emit<FILL>(p, p.n_cells, tri, 0.0f);

@@ -439,6 +439,7 @@ __device__ __forceinline__ DevMaterial load_material(const DevScene& sc, uint32_
 #ifndef RT_WF_GRID_WALK
 #define RT_WF_GRID_WALK 12
 #endif
+static_assert(EXT_EPS == RT_SG_EXT_EPS, "the light grids' dilation is derived from the shadow segments' origin offset");
 static_assert(RT_WF_GRID_WALK < RT_SG_SORTED_PREFIX, "a walk may only look at the ordered part of a list");
 #ifndef RT_WF_GRID_BLOCKS_PER_CU
 #define RT_WF_GRID_BLOCKS_PER_CU 16 /* 256-thread blocks per CU: 8 measured 3 % slower, 4 the same as 8 */

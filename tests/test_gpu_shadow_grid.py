@@ -164,3 +164,25 @@ def test_one_lane_and_two_lanes_give_the_same_frame(gpu_ctx):
                     frames[key] = (img, (st["rays"], st["shadow_rays"]))
         finally:
             del os.environ["RT_WF_LANES"]
+
+
+def test_slivers_and_needles(gpu_ctx):
+    """Long thin triangles (aspect 1e4 and more) and needles between the lights and a floor: the closest-point arithmetic behind a
+    triangle's key is least exact there, and a key must never exceed the triangle's true distance from the light."""
+    rng = np.random.default_rng(31)
+    n = 3000
+    a = rng.uniform(-3, 3, (n, 3)) + np.array([0, 0, -5.0])
+    long_dir = rng.normal(size=(n, 3))
+    long_dir /= np.linalg.norm(long_dir, axis=1, keepdims=True)
+    side = np.cross(long_dir, rng.normal(size=(n, 3)))
+    side /= np.linalg.norm(side, axis=1, keepdims=True)
+    length = rng.choice([0.5, 3.0, 12.0], n)[:, None]
+    width = rng.choice([1e-2, 1e-3, 1e-4], n)[:, None]
+    slivers = np.stack([a, a + long_dir * length, a + long_dir * length * rng.uniform(0, 1, (n, 1)) + side * width], 1)
+    floor, ids = _grid(6, 6, z=-9.0, size=14.0)
+    tris = np.concatenate([floor, slivers.astype(np.float32)])
+    lights = np.array([H.light_point((0.0, 0.0, -5.0), (1, 1, 1), 8.0), H.light_point((2.5, 2.0, -2.0), (1, 0.9, 0.8), 8.0),
+                       H.light_point(tuple(a[0] + long_dir[0] * 0.3), (1, 1, 1), 3.0),  # ON a needle
+                       H.light_directional((0.1, -0.2, -1.0), (1, 1, 1), 0.8)], dtype=T.LIGHT)
+    sc = _scene("slivers", tris, list(ids) + [int(i) % 4 for i in range(n)], lights=lights)
+    _same_frame(gpu_ctx, sc, 320, 240, 8, 4, min_answered=0.0)
