@@ -32,6 +32,8 @@ if ROOT not in sys.path:
 
 import numpy as np  # noqa: E402
 
+HEADLINE_FRAME_CRC = 4012668657  # CRC-32 of the float image of the default workload (sponza-like 1920x1080, 64 spp, 4 bounces): asserted against the
+                                 # oracle's crops in tests/test_gpu_baseline_configs.py and printed beside the measured one (config.frame_crc_expected)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 S_OUT_BYTES = 16 + 12 + 8  # per pixel: RGBA32F + three unorm8 texels + (prim id, t) hit record
 
@@ -294,6 +296,8 @@ def main():
 
     ctx = api.Context((local_rank,))
     ctx.upload_scene(scene)  # scene resident in HBM before the timed region
+    if mode_name == "extended":
+        ctx.prepare()        # ... and with it the light grids of the extended mode's shadow stage (rt_prepare; built lazily otherwise)
 
     part_world = args.share_of if (args.share_of > 1 and n_gpus == 1) else n_gpus
 
@@ -350,6 +354,7 @@ def main():
     # bytes that have to cross the HBM interface whatever the caches do: the path state, the pixels, the scene once
     compulsory_bytes = state_bytes + stc["pixels"] * S_OUT_BYTES + stc["scene_bytes"]
 
+    headline = (args.scene, args.width, args.height, spp, bounces, mode_name) == ("sponza_like", 1920, 1080, 64, 4, "extended") and part_world == n_gpus
     workload_key = f"{scene.name}_{args.width}x{args.height}_{mode_name}" + (f"_{spp}spp_{bounces}b" if mode_name == "extended" else "") + \
                    (f"_share{part_world}" if part_world != n_gpus else "")
     prof = load_profile(workload_key)
@@ -417,7 +422,7 @@ def main():
                        "paths_per_s": total_seg[0] / dt,
                        "segments_per_step": {"camera": total_seg[0] / args.steps, "continuation": total_seg[1] / args.steps, "shadow": total_seg[2] / args.steps},
                        "kernel_mrays_per_s_rank0": ext_segments / avg_kernel_ms / 1e3,
-                       "frame_crc": crc, "gather_ms": gather_ms,
+                       "frame_crc": crc, "frame_crc_expected": HEADLINE_FRAME_CRC if headline else None, "gather_ms": gather_ms,
                        "megakernel_fallback": bool(stc.get("flags", 0) & 1)},
             "roofline": roofline,
         }

@@ -22,11 +22,13 @@ FLAG_NO_SHADOWS = 2
 FLAG_KERNEL_V1 = 4
 FLAG_KERNEL_SM = 8
 FLAG_NO_SHADOW_GRID = 16
+FLAG_KERNEL_PIPELINE = 32
+PREPARE_SHADOW_GRIDS = 1
 EXTENDED_AVAILABLE = True
 
 # every symbol include/rt_hip.h declares
 ABI_SYMBOLS = [
-    "rt_create", "rt_upload_scene", "rt_upload_scene_packed", "rt_upload_textures", "rt_render", "rt_dispatch_tile",
+    "rt_create", "rt_upload_scene", "rt_upload_scene_packed", "rt_upload_textures", "rt_prepare", "rt_render", "rt_dispatch_tile",
     "rt_read_rgb32f", "rt_read_rgba8_channels", "rt_read_rgba8_combined", "rt_read_hits",
     "rt_get_stats", "rt_last_error", "rt_destroy", "rt_version",
 ]
@@ -127,14 +129,18 @@ class Context:
         td = np.ascontiguousarray(texture_data, dtype=np.uint8)
         self._check(self.lib.rt_upload_textures(self._h, _p(ti), C.c_uint32(len(ti)), _p(td), C.c_size_t(td.size)))
 
+    def prepare(self, what=PREPARE_SHADOW_GRIDS):
+        """rt_prepare: build ahead of time what the first extended-mode frame would otherwise build (the light grids)."""
+        self._check(self.lib.rt_prepare(self._h, C.c_uint32(what)))
+
     # -- rendering -------------------------------------------------------------------
     def render(self, width, height, camera, mode=MODE_LEGACY, spp=1, max_bounces=4, frame_seed=0, tile_size=0,
-               tile_rank=0, tile_world=1, counters=False, no_shadows=False, kernel_v1=False, kernel_sm=False, no_shadow_grid=False):
+               tile_rank=0, tile_world=1, counters=False, no_shadows=False, kernel_v1=False, kernel_sm=False, no_shadow_grid=False, kernel_pipeline=False):
         p = np.zeros((), dtype=T.RENDER_PARAMS)
         p["camera"] = camera
         p["width"], p["height"], p["spp"], p["max_bounces"], p["mode"] = width, height, spp, max_bounces, mode
         p["frame_seed"], p["tile_size"], p["tile_rank"], p["tile_world"] = frame_seed, tile_size, tile_rank, tile_world
-        p["flags"] = (FLAG_COUNTERS if counters else 0) | (FLAG_NO_SHADOWS if no_shadows else 0) | (FLAG_KERNEL_V1 if kernel_v1 else 0) | (FLAG_KERNEL_SM if kernel_sm else 0) | (FLAG_NO_SHADOW_GRID if no_shadow_grid else 0)
+        p["flags"] = (FLAG_COUNTERS if counters else 0) | (FLAG_NO_SHADOWS if no_shadows else 0) | (FLAG_KERNEL_V1 if kernel_v1 else 0) | (FLAG_KERNEL_SM if kernel_sm else 0) | (FLAG_NO_SHADOW_GRID if no_shadow_grid else 0) | (FLAG_KERNEL_PIPELINE if kernel_pipeline else 0)
         self._check(self.lib.rt_render(self._h, _p(p)))
         self.width, self.height = width, height
         return self.stats()

@@ -560,7 +560,11 @@ void collapse8(std::vector<TmpNode>& nodes, std::vector<uint32_t>& ids, uint32_t
             const float wide = opt.cost_traverse8 * area + dist[W8];
             const uint32_t cnt = sub_count[f.node];
             const float leafc = cnt && cnt <= max_leaf ? opt.cost_intersect * (float)cnt * area : inf;
-            d.leaf = leafc <= wide ? 1 : 0;
+            // Finite coordinates whose box area overflows f32 (~1e19 and beyond) make every cost inf or NaN: no `v < dist` above
+            // succeeds and arg stays 0, which is not a split.  The rule then is explicit, the same in device_build.hip:
+            // a leaf only when the count allows it, else a wide node split 1 : 7 - a poor tree, but a valid one.
+            if (arg[W8] == 0) arg[W8] = 1;
+            d.leaf = (cnt && cnt <= max_leaf && !(wide < leafc)) ? 1 : 0;
             d.c[0] = std::min(leafc, wide);
             d.split[0] = arg[W8];
             for (int k = 2; k <= W8; k++) {

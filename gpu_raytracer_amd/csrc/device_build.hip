@@ -306,7 +306,9 @@ __global__ __launch_bounds__(256) void k_db_merge(DbArrays A, const uint32_t* __
     DbDp d;
     d.count = min(dl.count + dr.count, 1u << 20);
     const float leafc = d.count <= max_leaf ? cost_intersect * (float)d.count * area : INFINITY;
-    d.leaf = leafc <= wide ? 1u : 0u;
+    // costs that are all inf / NaN (box areas beyond f32) leave arg at 0, which is not a split: same explicit rule as collapse8 (bvh_builder.cpp)
+    if (arg[DB_W] == 0) arg[DB_W] = 1;
+    d.leaf = (d.count <= max_leaf && !(wide < leafc)) ? 1u : 0u;
     d.c[0] = fminf(leafc, wide);
     d.split[0] = arg[DB_W];
     for (int k = 2; k <= DB_W; k++) {

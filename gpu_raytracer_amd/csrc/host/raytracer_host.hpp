@@ -445,6 +445,8 @@ class BvhBuilder {
         }
         return triangles.size() > 100000 ? build_chunked(triangles, vertices) : build_standard(triangles, vertices);
     }
+    // BvhBuilder::triangle_aabb, src/bvh.rs:272-275 (private there, exercised by its own test :510-523): the box build_chunked unions per triangle
+    static Aabb triangle_aabb(const Triangle& t, const Vertex* vertices) { return triangle::bounding_box(t, vertices); }
 
   private:
     static BvhResult build_chunked(const std::vector<Triangle>& triangles, const std::vector<Vertex>& vertices) {
@@ -454,7 +456,7 @@ class BvhBuilder {
         for (size_t base = 0; base < triangles.size(); base += per_leaf) {
             const size_t len = std::min(per_leaf, triangles.size() - base);
             Aabb box = aabb::empty();
-            for (size_t i = 0; i < len; i++) box = aabb::union_(box, triangle::bounding_box(triangles[base + i], vertices.data()));
+            for (size_t i = 0; i < len; i++) box = aabb::union_(box, triangle_aabb(triangles[base + i], vertices.data()));
             const uint32_t start = (uint32_t)r.triangle_indices.size();
             for (size_t i = 0; i < len; i++) r.triangle_indices.push_back((uint32_t)(base + i));
             level.push_back(bvh_node::leaf(box, start, (uint32_t)len));

@@ -25,6 +25,9 @@
 #include "shadow_grid.h"
 #include "wavefront.h"
 
+#ifndef RT_SINGLE_PASS_MAX_NODES
+#define RT_SINGLE_PASS_MAX_NODES 64u /* "BVH depth <= 4" scenes of BASELINE configs[1]; larger scenes: measured in profiles/ab_r03.json */
+#endif
 #define RT_DEVICE_BUILD_MIN_TRIS 1024u /* below this the host build takes well under a millisecond */
 
 namespace {
@@ -55,6 +58,7 @@ struct DeviceState {
     DevShadowGrid* grids = nullptr;                        // one per light (shadow_grid.h), null when no light has a grid
     std::vector<void*> grid_allocs;
     std::vector<rt::ShadowGridBuild> grid_info;
+    bool grids_tried = false;                              // the light grids of the current scene were built (or refused) on this device
     rt::WfBuffers wf{};                                    // wavefront pipeline state (extended mode)
     rt::WfBuffers wf2{};                                   // ... of the second lane (its own path state, queues and counters; the pixel sums are shared)
     std::vector<void*> wf2_allocs;
@@ -81,6 +85,8 @@ struct rt_ctx {
     int fail_upload_at = -1;          // test hook: the next scene upload fails before its k-th device array (rt_debug_fail_upload)
     uint32_t n_input_tris = 0;        // triangles handed to the last scene upload (prim ids are < this)
     int build_method = 0;             // how its tree was built: 0 host SAH, 1 host PLOC, 2 device PLOC
+    std::vector<DevLight> host_lights; // what the lazy light-grid build needs of the last upload: the lights, ...
+    float box_lo[3] = {0, 0, 0}, box_hi[3] = {0, 0, 0}; // ... the box of the triangles with finite vertices
     uint32_t n_textures = 0;          // bindings 6-7 as last handed over (rt_upload_textures); never sampled, like the reference
     uint64_t texture_bytes = 0;
 
@@ -122,7 +128,7 @@ void free_scene(DeviceState& d) {
     d.grid_allocs.clear();
     d.grid_info.clear();
     d.grids = nullptr;
-
+    d.grids_tried = false;
 }
 void free_targets(DeviceState& d) {
     (void)hipSetDevice(d.device);
@@ -360,12 +366,6 @@ int upload_common(rt_ctx* ctx, const rt_sphere* spheres, uint32_t n_spheres, con
         for (int k = 0; k < 3; k++)
             for (int a = 0; a < 3; a++) box_lo[a] = std::min(box_lo[a], vs[k][a]), box_hi[a] = std::max(box_hi[a], vs[k][a]);
     }
-    bool grids_on = true;
-    rt::ShadowGridOptions gopt;
-    if (const char* e = std::getenv("RT_SHADOW_GRID")) grids_on = std::atoi(e) != 0;
-    if (const char* e = std::getenv("RT_SHADOW_GRID_RES")) gopt.res_point = (uint32_t)std::atoi(e), gopt.res_dir = 2u * (uint32_t)std::atoi(e); // development knobs
-    if (const char* e = std::getenv("RT_SHADOW_GRID_HEAVY")) gopt.heavy = (uint32_t)std::atoi(e);
-    if (const char* e = std::getenv("RT_SHADOW_GRID_MEAN")) gopt.max_mean_list = std::atof(e), gopt.max_heavy_share = 1.0; // (forces grids onto cluttered scenes)
     auto upload_all = [&](DeviceState& d) -> int {
         HIPCHK(ctx, hipSetDevice(d.device));
         int rc;
@@ -388,34 +388,6 @@ int upload_common(rt_ctx* ctx, const rt_sphere* spheres, uint32_t n_spheres, con
         if ((rc = upload_array(ctx, &d.materials, dm)) != RT_OK) return rc;
         // the copies went through the null stream and d.stream is non-blocking: make the order explicit
         HIPCHK(ctx, hipDeviceSynchronize());
-        // Per-light triangle lists for the shadow segments of the wavefront pipeline (shadow_grid.h), rasterised on the device from
-        // the triangle records just placed.  RT_SHADOW_GRID=0 switches them off (every shadow segment then walks the BVH).
-        if (grids_on && n_lights > 0 && n_lights <= RT_WF_MAX_LIGHTS && tree_tris > 0) {
-            std::vector<DevShadowGrid> hg(n_lights);
-            bool any = false;
-            size_t free_b = 0, total_b = 0;
-            HIPCHK(ctx, hipMemGetInfo(&free_b, &total_b));
-            rt::ShadowGridOptions lopt = gopt; // all grids together may take a quarter of what is free now
-            lopt.max_entries = std::min<uint64_t>(gopt.max_entries, free_b / 4 / n_lights / (RT_SG_ENTRY_QUADS * sizeof(uint4))); // (+ 128 bytes per cell: at most 0.8 GB per light)
-            for (uint32_t i = 0; i < n_lights; i++) {
-                rt::ShadowGridBuild gb;
-                const hipError_t e = rt::shadow_grid_build(d.tris, tree_tris, dl[i], box_lo, box_hi, lopt, d.stream, &gb);
-                if (e != hipSuccess) { // out of memory for a grid is not an error: the BVH answers for this light
-                    (void)hipGetLastError();
-                    gb = rt::ShadowGridBuild{};
-                }
-                hg[i] = gb.grid;
-                if (gb.blocks) d.grid_allocs.push_back(gb.blocks);
-                if (gb.overflow) d.grid_allocs.push_back(gb.overflow);
-                any = any || gb.grid.kind != RT_SG_KIND_NONE;
-                d.grid_info.push_back(gb);
-            }
-            if (any) {
-                if ((rc = upload_array(ctx, &d.grids, hg)) != RT_OK) return rc;
-                d.grid_allocs.push_back(d.grids);
-                HIPCHK(ctx, hipDeviceSynchronize());
-            }
-        }
         return RT_OK;
     };
     for (auto& d : ctx->devs) {
@@ -450,8 +422,67 @@ int upload_common(rt_ctx* ctx, const rt_sphere* spheres, uint32_t n_spheres, con
     ctx->stats.n_devices = (uint32_t)ctx->devs.size();
     ctx->stats.n_textures = ctx->n_textures;
     ctx->stats.texture_bytes = ctx->texture_bytes;
+    ctx->host_lights = dl; // the light grids of the extended mode's shadow stage are built when a frame first needs them (ensure_grids)
+    for (int a = 0; a < 3; a++) ctx->box_lo[a] = box_lo[a], ctx->box_hi[a] = box_hi[a];
     ctx->uploaded = true;
     ctx->frame_valid = false;
+    return RT_OK;
+}
+
+// Per-light triangle lists for the shadow segments of the wavefront pipeline (shadow_grid.h), rasterised on the device from the
+// triangle records of the uploaded scene.  LAZY: the reference's flow (src/scene.rs:87-119 replace_with_gltf, then
+// src/compute.rs:12-50 every frame) only ever renders modes 0/1, which trace no shadow segments, so rt_upload_scene* builds
+// nothing; the first extended-mode frame that traces shadow segments through the pipeline pays the build once per scene (or the
+// caller asks for it ahead of time: rt_prepare).  rt_stats reports what it cost (grid_build_ms) and holds (grid_bytes).
+// RT_SHADOW_GRID=0 and the RT_SHADOW_GRID_* variables are development knobs only.
+int ensure_grids(rt_ctx* ctx, DeviceState& d) {
+    if (d.grids_tried) return RT_OK;
+    d.grids_tried = true;
+    const uint32_t n_lights = (uint32_t)ctx->host_lights.size(), tree_tris = ctx->scene_counts.n_tris;
+    bool grids_on = true;
+    rt::ShadowGridOptions gopt;
+    if (const char* e = std::getenv("RT_SHADOW_GRID")) grids_on = std::atoi(e) != 0;
+    if (const char* e = std::getenv("RT_SHADOW_GRID_RES")) gopt.res_point = (uint32_t)std::atoi(e), gopt.res_dir = 2u * (uint32_t)std::atoi(e);
+    if (const char* e = std::getenv("RT_SHADOW_GRID_HEAVY")) gopt.heavy = (uint32_t)std::atoi(e);
+    if (const char* e = std::getenv("RT_SHADOW_GRID_MEAN")) gopt.max_mean_list = std::atof(e), gopt.max_heavy_share = 1.0; // (forces grids onto cluttered scenes)
+    if (!grids_on || n_lights == 0 || n_lights > RT_WF_MAX_LIGHTS || tree_tris == 0) return RT_OK;
+    const double t0 = now_ms();
+    HIPCHK(ctx, hipSetDevice(d.device));
+    HIPCHK(ctx, hipStreamSynchronize(d.stream));
+    std::vector<DevShadowGrid> hg(n_lights);
+    bool any = false;
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(ctx, hipMemGetInfo(&free_b, &total_b));
+    // all grids together may take a quarter of what is free now - cell blocks (128 bytes per cell: 0.8 GB per cube map at 1024 cells
+    // per face side) AND list entries count against it (only the entries did); a light whose grid would not fit gets none
+    rt::ShadowGridOptions lopt = gopt;
+    lopt.max_bytes = free_b / 4 / n_lights;
+    lopt.max_entries = std::min<uint64_t>(gopt.max_entries, lopt.max_bytes / (RT_SG_ENTRY_QUADS * sizeof(uint4)));
+    uint64_t bytes = 0;
+    for (uint32_t i = 0; i < n_lights; i++) {
+        rt::ShadowGridBuild gb;
+        const hipError_t e = rt::shadow_grid_build(d.tris, tree_tris, ctx->host_lights[i], ctx->box_lo, ctx->box_hi, lopt, d.stream, &gb);
+        if (e != hipSuccess) { // out of memory for a grid is not an error: the BVH answers for this light
+            (void)hipGetLastError();
+            gb = rt::ShadowGridBuild{};
+        }
+        hg[i] = gb.grid;
+        if (gb.blocks) d.grid_allocs.push_back(gb.blocks);
+        if (gb.overflow) d.grid_allocs.push_back(gb.overflow);
+        if (gb.grid.kind != RT_SG_KIND_NONE) bytes += gb.bytes;
+        any = any || gb.grid.kind != RT_SG_KIND_NONE;
+        d.grid_info.push_back(gb);
+    }
+    if (any) {
+        int rc;
+        if ((rc = upload_array(ctx, &d.grids, hg)) != RT_OK) return rc;
+        d.grid_allocs.push_back(d.grids);
+        HIPCHK(ctx, hipDeviceSynchronize());
+    }
+    if (&d == &ctx->devs[0]) { // (every device holds the same grids)
+        ctx->stats.grid_bytes = bytes;
+        ctx->stats.grid_build_ms = now_ms() - t0;
+    }
     return RT_OK;
 }
 
@@ -461,10 +492,16 @@ int ensure_wavefront(rt_ctx* ctx, DeviceState& d, uint32_t n_blocks, uint32_t ba
     // overflow entries (64-bit) per lane beyond the LDS part of the stack
     const uint32_t ovf_entries = ctx->scene_counts.stack_entries + 2u > RT_WF8_LDS_STACK ? ctx->scene_counts.stack_entries + 2u - RT_WF8_LDS_STACK : 1u;
     if (d.wf.capacity >= capacity && d.wf.n_blocks == n_blocks && d.wf.batch == batch && d.wf_lights >= n_lights && d.wf.counters &&
-        d.wf.ovf_entries >= ovf_entries && (!two_lanes || d.wf2.counters))
+        d.wf.ovf_entries >= ovf_entries && d.wf.stack_ovf && (!two_lanes || (d.wf2.counters && d.wf2.capacity >= capacity && d.wf2.stack_ovf)))
         return RT_OK;
     free_wavefront(d);
     HIPCHK(ctx, hipSetDevice(d.device));
+    // an allocation that fails half way must not leave a lane that looks complete to the reuse test above
+    struct Guard {
+        DeviceState& d;
+        bool ok = false;
+        ~Guard() { if (!ok) free_wavefront(d); }
+    } guard{d};
     for (int lane = 0; lane < (two_lanes ? 2 : 1); lane++) {
     std::vector<void*>& owned = lane ? d.wf2_allocs : d.wf_allocs;
     auto alloc = [&](void** p, size_t bytes) -> hipError_t {
@@ -504,6 +541,7 @@ int ensure_wavefront(rt_ctx* ctx, DeviceState& d, uint32_t n_blocks, uint32_t ba
     w.capacity = capacity;
     }
     d.wf_lights = n_lights;
+    guard.ok = true;
     return RT_OK;
 }
 
@@ -530,13 +568,19 @@ uint32_t wavefront_batch(uint32_t n_blocks, uint32_t spp, uint32_t n_lights, siz
     uint64_t target_paths = 64ull << 20;
     if (const char* e = std::getenv("RT_WF_TARGET_PATHS")) target_paths = std::max<uint64_t>(1, std::strtoull(e, nullptr, 10));
     const uint64_t lights = std::max(1u, n_lights);
-    const uint64_t bytes_per_path = 8 * 16 + 4 + 2 * 16 + 16 * lights; // path state, vis, pxy, two extension queues, shadow queue (4 slots per entry)
+    const uint64_t bytes_per_path = 8 * 16 + 4 + 2 * 16 + 16 * lights + 4 * lights; // path state, vis, pxy, two extension queues, shadow queue (4 slots per entry), the handed-on shadow queue (dense)
     target_paths = std::min<uint64_t>(target_paths, free_bytes / 2 / bytes_per_path);
     target_paths = std::min<uint64_t>(target_paths, wavefront_max_paths(n_lights));
     uint32_t max_batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(spp, target_paths / per_sample));
     if (two_lanes && spp >= 2) max_batch = std::min(max_batch, (spp + 1) / 2); // two lanes want two batches, also of a frame that would fit one
     const uint32_t n_batches = (spp + max_batch - 1) / max_batch;
     return std::max(1u, (spp + n_batches - 1) / std::max(1u, n_batches));
+}
+
+// Largest tree (8-wide nodes) whose primary-rays-only frames take the one-pass kernel instead of the queue pipeline (run_frame).
+uint32_t single_pass_max_nodes() {
+    if (const char* e = std::getenv("RT_SINGLE_PASS_MAX_NODES")) return (uint32_t)std::strtoul(e, nullptr, 10); // development knob
+    return RT_SINGLE_PASS_MAX_NODES;
 }
 
 // rt_dispatch_tile returns after the launch, like `queue.submit` in src/compute.rs:165.  Whatever needs the result or
@@ -564,6 +608,19 @@ int run_frame(rt_ctx* ctx, DevFrame fr, bool counters, uint32_t world, uint32_t 
     size_t nd = single_tile ? 1 : ctx->devs.size();
     uint32_t total_tiles = fr.tiles_x * fr.tiles_y;
     bool fallback = false; // the extended mode was asked for its default (queue) pipeline and got the megakernel
+    bool single = false;   // ... took the one-pass kernel by rule (primary rays only, tiny tree)
+    struct WfRun { // one device's walk through the batches and bounces of its share of a wavefront-pipeline frame
+        enum Phase { GENERATE, BOUNCE, RESOLVE, DONE };
+        size_t dev = 0;
+        DevFrame f{};
+        DevScene dsc{};
+        uint32_t batch = 1, first = 0, j = 0, it = 0, alive = 0;
+        bool two = false;
+        Phase phase = GENERATE;
+        hipStream_t poll_stream = nullptr;
+    };
+    std::vector<WfRun> runs;
+    runs.reserve(nd); // (polls hold pointers into it)
     for (size_t j = 0; j < nd; j++) {
         DeviceState& d = ctx->devs[j];
         HIPCHK(ctx, hipSetDevice(d.device));
@@ -584,11 +641,23 @@ int run_frame(rt_ctx* ctx, DevFrame fr, bool counters, uint32_t world, uint32_t 
         HIPCHK(ctx, hipEventRecord(d.ev0, d.stream));
         // the queue-based pipeline needs one visibility bit per light and every path slot of ONE sample per owned pixel block
         // addressable; anything else (more than 32 lights, a single device's share beyond ~134 M pixels) takes the megakernel
-        const bool wavefront = f.mode == RT_MODE_EXTENDED && !(f.flags & (RT_FLAG_KERNEL_V1 | RT_FLAG_KERNEL_SM)) &&
+        // Primary rays only over a tiny tree (BASELINE configs[1]: Cornell, 12 triangles, max_bounces 0): the queue pipeline would move
+        // 132 bytes of path state per sample through six kernels for a closest hit that costs a few dozen instructions (measured 15.9 ms
+        // and 46.7 GB of HBM traffic per 1080p 64-spp frame); the nested-loop kernel loops the pixel's samples in registers, traces the
+        // closest hit and the per-light shadow segments inline and stores the pixel once: 2.6 ms, same bits (the per-sample order is
+        // fixed by the CPU statement).  SURVEY 7 step 6, shader/src/lib.rs:86-88 (one write per pixel).  RT_FLAG_KERNEL_PIPELINE keeps the pipeline.
+        const bool single_pass = f.mode == RT_MODE_EXTENDED && !(f.flags & (RT_FLAG_KERNEL_V1 | RT_FLAG_KERNEL_SM | RT_FLAG_KERNEL_PIPELINE)) && f.max_bounce == 0 &&
+                                 ctx->scene_counts.n_nodes <= single_pass_max_nodes();
+        if (single_pass) single = true;
+        const bool wavefront = f.mode == RT_MODE_EXTENDED && !(f.flags & (RT_FLAG_KERNEL_V1 | RT_FLAG_KERNEL_SM)) && !single_pass &&
                                ctx->scene_counts.n_lights <= RT_WF_MAX_LIGHTS &&
                                (uint64_t)f.n_owned_tiles * rt::blocks_per_tile(f.tile_size) * 64u <= wavefront_max_paths(ctx->scene_counts.n_lights);
-        if (f.mode == RT_MODE_EXTENDED && !wavefront && !(f.flags & (RT_FLAG_KERNEL_V1 | RT_FLAG_KERNEL_SM))) fallback = true;
+        if (f.mode == RT_MODE_EXTENDED && !wavefront && !single_pass && !(f.flags & (RT_FLAG_KERNEL_V1 | RT_FLAG_KERNEL_SM))) fallback = true;
         if (wavefront) {
+            if (!(f.flags & (RT_FLAG_NO_SHADOW_GRID | RT_FLAG_NO_SHADOWS))) { // the first frame that traces shadow segments through the pipeline builds the light grids
+                rc = ensure_grids(ctx, d);
+                if (rc != RT_OK) return rc;
+            }
             const uint32_t n_blocks = f.n_owned_tiles * rt::blocks_per_tile(f.tile_size);
             size_t free_b = 0, total_b = 0;
             HIPCHK(ctx, hipMemGetInfo(&free_b, &total_b));
@@ -613,32 +682,17 @@ int run_frame(rt_ctx* ctx, DevFrame fr, bool counters, uint32_t world, uint32_t 
                 HIPCHK(ctx, hipStreamWaitEvent(d.stream2, d.ev_start, 0));
                 HIPCHK(ctx, hipMemsetAsync(d.wf2.totals, 0, 16 * sizeof(unsigned long long), d.stream2));
             }
-            const DevScene dsc = scene_for(ctx, d);
             d.wf.grids = d.wf2.grids = (f.flags & RT_FLAG_NO_SHADOW_GRID) ? nullptr : d.grids;
-            uint32_t j = 0;
-            for (uint32_t first = 0; first < f.spp; first += batch, j++) {
-                const uint32_t n = std::min(batch, f.spp - first);
-                const uint32_t lane = two ? (j & 1u) : 0u;
-                rt::WfBuffers& w = lane ? d.wf2 : d.wf;
-                hipStream_t st = lane ? d.stream2 : d.stream;
-                HIPCHK(ctx, rt::wf_generate(dsc, f, w, first, n, st));
-                for (uint32_t it = 0; it <= f.max_bounce; it++) {
-                    HIPCHK(ctx, rt::wf_bounce(dsc, f, w, it, counters, st));
-                    if ((it & 7u) == 7u && it < f.max_bounce) { // long paths: stop as soon as every path has ended
-                        uint32_t alive = 0;
-                        HIPCHK(ctx, hipMemcpyAsync(&alive, w.counters + rt::WF_EXT_COUNT, 4, hipMemcpyDeviceToHost, st));
-                        HIPCHK(ctx, hipStreamSynchronize(st));
-                        if (alive == 0) break;
-                    }
-                }
-                if (two && j > 0) HIPCHK(ctx, hipStreamWaitEvent(st, d.ev_res[(j - 1u) & 1u], 0));
-                HIPCHK(ctx, rt::wf_resolve(f, w, targets_for(d), n, first == 0, first + n >= f.spp, st));
-                if (two) HIPCHK(ctx, hipEventRecord(d.ev_res[j & 1u], st));
-            }
-            if (two) { // the frame ends when both lanes have
-                HIPCHK(ctx, hipEventRecord(d.ev_join, d.stream2));
-                HIPCHK(ctx, hipStreamWaitEvent(d.stream, d.ev_join, 0));
-            }
+            { const char* pe = std::getenv("RT_WF_PROBE"); d.wf.probe = d.wf2.probe = pe ? (uint32_t)std::atoi(pe) : 0u; }
+            // the launches themselves follow below, one step per device in turn (WfRun): a device's every-8-bounces read-back of its live
+            // paths must not hold back the launches of the next device (it was inside this loop)
+            WfRun r;
+            r.dev = j;
+            r.f = f;
+            r.dsc = scene_for(ctx, d);
+            r.batch = batch;
+            r.two = two;
+            runs.push_back(r);
             d.used_two_lanes = two;
             d.used_wavefront = true;
         } else if (f.mode == RT_MODE_EXTENDED) {
@@ -646,7 +700,58 @@ int run_frame(rt_ctx* ctx, DevFrame fr, bool counters, uint32_t world, uint32_t 
             HIPCHK(ctx, rt::launch_render_extended(scene_for(ctx, d), f, targets_for(d), counters, d.stream));
         } else
             HIPCHK(ctx, rt::launch_render_reference(scene_for(ctx, d), f, targets_for(d), counters, d.stream));
-        HIPCHK(ctx, hipEventRecord(d.ev1, d.stream));
+        if (!wavefront) HIPCHK(ctx, hipEventRecord(d.ev1, d.stream));
+    }
+    // The wavefront pipeline's launches: every device advances by one step (a batch's generation, one bounce, a batch's resolve) in
+    // turn, so that several devices of one context fill up side by side; the devices that have just passed a multiple of 8 bounces are
+    // then polled together ("long paths: stop as soon as every path has ended").
+    for (bool busy = !runs.empty(); busy;) {
+        busy = false;
+        std::vector<WfRun*> polls;
+        for (WfRun& r : runs) {
+            if (r.phase == WfRun::DONE) continue;
+            busy = true;
+            DeviceState& d = ctx->devs[r.dev];
+            HIPCHK(ctx, hipSetDevice(d.device));
+            const uint32_t n = std::min(r.batch, r.f.spp - r.first);
+            const uint32_t lane = r.two ? (r.j & 1u) : 0u;
+            rt::WfBuffers& w = lane ? d.wf2 : d.wf;
+            hipStream_t st = lane ? d.stream2 : d.stream;
+            if (r.phase == WfRun::GENERATE) {
+                HIPCHK(ctx, rt::wf_generate(r.dsc, r.f, w, r.first, n, st));
+                r.it = 0;
+                r.phase = WfRun::BOUNCE;
+            } else if (r.phase == WfRun::BOUNCE) {
+                HIPCHK(ctx, rt::wf_bounce(r.dsc, r.f, w, r.it, counters, st));
+                if (r.it >= r.f.max_bounce) r.phase = WfRun::RESOLVE;
+                else if ((r.it & 7u) == 7u) {
+                    HIPCHK(ctx, hipMemcpyAsync(&r.alive, w.counters + rt::WF_EXT_COUNT, 4, hipMemcpyDeviceToHost, st));
+                    r.poll_stream = st;
+                    polls.push_back(&r);
+                } else r.it++;
+            } else { // RESOLVE
+                if (r.two && r.j > 0) HIPCHK(ctx, hipStreamWaitEvent(st, d.ev_res[(r.j - 1u) & 1u], 0));
+                HIPCHK(ctx, rt::wf_resolve(r.f, w, targets_for(d), n, r.first == 0, r.first + n >= r.f.spp, st));
+                if (r.two) HIPCHK(ctx, hipEventRecord(d.ev_res[r.j & 1u], st));
+                r.first += r.batch;
+                r.j++;
+                if (r.first < r.f.spp) r.phase = WfRun::GENERATE;
+                else {
+                    if (r.two) { // the frame ends when both lanes have
+                        HIPCHK(ctx, hipEventRecord(d.ev_join, d.stream2));
+                        HIPCHK(ctx, hipStreamWaitEvent(d.stream, d.ev_join, 0));
+                    }
+                    HIPCHK(ctx, hipEventRecord(d.ev1, d.stream));
+                    r.phase = WfRun::DONE;
+                }
+            }
+        }
+        for (WfRun* r : polls) { // (after every device has its next launches queued)
+            HIPCHK(ctx, hipSetDevice(ctx->devs[r->dev].device));
+            HIPCHK(ctx, hipStreamSynchronize(r->poll_stream));
+            if (r->alive == 0) r->phase = WfRun::RESOLVE;
+            else r->it++;
+        }
     }
     double kernel_ms = 0.0;
     unsigned long long cnt[16] = {0}, grid_cnt[2] = {0, 0};
@@ -685,7 +790,9 @@ int run_frame(rt_ctx* ctx, DevFrame fr, bool counters, uint32_t world, uint32_t 
             cnt[5] += t[2];
             cnt[1] += t[3];
             cnt[2] += t[4];
-            if (t[WF_TOTAL_ERROR] != 0) return ctx->fail(RT_ERR_INTERNAL, "wavefront pipeline: a queue reservation exceeded its allocation (frame discarded)");
+            if (t[WF_TOTAL_ERROR] != 0)
+                return ctx->fail(RT_ERR_INTERNAL, "wavefront pipeline: %s (frame discarded)",
+                                 (t[WF_TOTAL_ERROR] & 2ull) ? "a traversal stack grew beyond the depth the tree reports" : "a queue reservation exceeded its allocation");
             cnt[8] = std::max(cnt[8], t[5]); // diagnostics: stack high-water mark, visits with > 16 / > 24 entries
             cnt[9] += t[6];
             cnt[10] += t[7];
@@ -727,7 +834,7 @@ int run_frame(rt_ctx* ctx, DevFrame fr, bool counters, uint32_t world, uint32_t 
     for (int k = 0; k < 2; k++) ctx->grid_diag[k] = counters ? grid_cnt[k] : 0;
     st.kernel_ms = kernel_ms;
     st.wall_ms = now_ms() - w0;
-    st.flags = fallback ? RT_STAT_MEGAKERNEL_FALLBACK : 0u;
+    st.flags = (fallback ? RT_STAT_MEGAKERNEL_FALLBACK : 0u) | (single ? RT_STAT_SINGLE_PASS : 0u);
     return RT_OK;
 }
 
@@ -964,6 +1071,17 @@ unsigned long long rt_debug_queue_slots(unsigned long long max_entries, uint32_t
     return rt::wf_queue_slots_for((size_t)max_entries, per_lane, (size_t)waves);
 }
 uint32_t rt_debug_pick_window(uint32_t iterations, uint32_t per_lane) { return rt::wf_pick_window(iterations, per_lane); }
+
+int rt_prepare(rt_ctx* ctx, uint32_t what) {
+    if (!ctx) return RT_ERR_BAD_ARG;
+    if (!ctx->uploaded) return ctx->fail(RT_ERR_NOT_UPLOADED, "rt_prepare: no scene uploaded");
+    if (what & ~RT_PREPARE_SHADOW_GRIDS) return ctx->fail(RT_ERR_BAD_ARG, "rt_prepare: unknown bits 0x%x", what & ~RT_PREPARE_SHADOW_GRIDS);
+    if (int rcp = sync_pending(ctx)) return rcp;
+    if (what & RT_PREPARE_SHADOW_GRIDS)
+        for (auto& d : ctx->devs)
+            if (int rc = ensure_grids(ctx, d)) return rc;
+    return RT_OK;
+}
 
 int rt_render(rt_ctx* ctx, const rt_render_params* p) {
     if (!ctx) return RT_ERR_BAD_ARG;

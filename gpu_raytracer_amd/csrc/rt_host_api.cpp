@@ -241,6 +241,13 @@ int rt_host_bvh_triangle(const rt_triangle* triangle, const rt_vertex* vertices,
     return RT_OK;
 }
 
+int rt_host_triangle_aabb(const rt_triangle* triangle, const rt_vertex* vertices, uint32_t n_vertices, rt_aabb* box) {
+    if (!triangle || !vertices || !box) return RT_ERR_BAD_ARG;
+    if (triangle->v0_index >= n_vertices || triangle->v1_index >= n_vertices || triangle->v2_index >= n_vertices) return RT_ERR_BAD_ARG;
+    *box = BvhBuilder::triangle_aabb(*triangle, vertices);
+    return RT_OK;
+}
+
 void rt_host_progressive_timing(double out[7]) {
     for (int i = 0; i < 7; i++) out[i] = g_timing[i];
 }

@@ -70,6 +70,7 @@ struct ShadowGridOptions {
     uint32_t res_dir = 2048;     // cells per side of an orthographic grid
     uint32_t heavy = 64;         // longest list a segment walks itself
     uint64_t max_entries = 400ull << 20; // per light; beyond it the light gets no grid
+    uint64_t max_bytes = ~0ull;  // per light, cell blocks + list entries; a grid that would take more is refused (before anything of it is allocated)
     double max_mean_list = 9.0;  // entries per filled cell ...
     double max_heavy_share = 0.01; // ... and share of cells over `heavy` beyond which a grid does not pay (shadow_grid.hip)
 };

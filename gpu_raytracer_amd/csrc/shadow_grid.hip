@@ -477,6 +477,10 @@ hipError_t shadow_grid_build(const DevTri* d_tris, uint32_t n_records, const Dev
         return hipSuccess; // no grid for this light
     }
     const size_t block_bytes = (size_t)p.n_cells * RT_SG_BLOCK_QUADS * sizeof(uint4), ovf_bytes = ((size_t)tail[1] + 1) * RT_SG_ENTRY_QUADS * sizeof(uint4);
+    if ((uint64_t)block_bytes + ovf_bytes > opt.max_bytes) { // the caller's memory budget: no grid, the BVH answers for this light
+        cleanup();
+        return hipSuccess;
+    }
     SG_CHK(hipMalloc((void**)&blocks, block_bytes));
     SG_CHK(hipMalloc((void**)&overflow, ovf_bytes));
     SG_CHK(hipMemsetAsync(blocks, 0, block_bytes, stream)); // (an untouched cell is an empty list)

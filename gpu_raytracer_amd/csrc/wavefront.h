@@ -29,6 +29,7 @@ enum WfCounter : uint32_t {
     WF_EXT_WINDOW_NEXT = 8, // ... the next extension queue
     WF_SHADOW2_CURSOR = 9,
     WF_SHADOW2_WINDOW = 10, // stays 0: the handed-on queue is written densely
+    WF_FINISH_DONE = 11,    // blocks of k_wf_finish that have ended (the last one advances the queues)
     WF_N_COUNTERS = 12
 };
 
@@ -59,6 +60,7 @@ struct WfBuffers {
     uint32_t n_blocks;   // 8x8 pixel blocks owned by this device
     uint32_t batch;      // samples per pixel in flight
     uint32_t capacity;   // path slots
+    uint32_t probe;      // development probes of the counting kernel variants (RT_WF_PROBE), 0 otherwise
 };
 
 #define WF_TOTAL_ERROR 15 /* totals[] slot: non-zero = a queue reservation did not fit; every later stage kernel of the frame returns at once */

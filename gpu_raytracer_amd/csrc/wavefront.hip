@@ -10,7 +10,7 @@
 //   k_wf_trace<any hit>  persistent; shadow segments walk the BVH and set the same visibility bits
 //   k_wf_finish          sum the visible contributions IN LIGHT ORDER, add emission, then terminal shading or
 //                        continuation sampling + russian roulette; survivors go to the next extension queue
-//   k_wf_advance         one thread: totals += queue sizes, swap queues, reset cursors
+//                        ; the last block to end moves the queue sizes on and resets the cursors (wf_advance)
 // Per-path arithmetic and its order are exactly those of the CPU statement (and of the megakernels in
 // kernels.hip); queues only change WHEN a path's next step runs, so images stay bit-identical.
 #include "wavefront.h"
@@ -213,6 +213,8 @@ __global__ __launch_bounds__(WAVE, RT_WF8_MIN_WAVES) void k_wf_trace(DevScene sc
     Counts cnt = {0u, 0u};
     int sp_max = 0;
     uint32_t d_node_steps = 0, d_leaf_steps = 0, d_leaf_lanes = 0, d_leaf_trips = 0, d_refills = 0;
+    uint32_t d_empty = 0, d_entered = 0; // counting variant: visits that enter no child, children entered
+    bool second = false;                 // counting variant, RT_WF_PROBE=1: the segment's second walk, started with its own hit distance (only that walk is counted)
 
     bool active = false, exhausted = false;
     uint32_t chunk_next = 0, chunk_end = 0;
@@ -326,10 +328,15 @@ __global__ __launch_bounds__(WAVE, RT_WF8_MIN_WAVES) void k_wf_trace(DevScene sc
                 if (can_node) {
                     uint32_t cb, tb, im, lm;
                     const uint32_t hm = visit_node8<COUNT>(nodes, cur, fray, hit.t, cnt, cb, tb, im, lm);
+                    if (COUNT) {
+                        if (wb.probe && !ANY && !second) cnt.nodes--;
+                        else d_empty += hm == 0u ? 1u : 0u, d_entered += (uint32_t)__popc(hm);
+                    }
                     cur = WF8_NONE;
                     if (g_bits & 0xFFu) { // siblings still to visit: park them
                         if (sp < RT_WF8_LDS_STACK) stack[sp * WAVE] = make_uint2(g_base, g_bits);
-                        else ovf[(sp - RT_WF8_LDS_STACK) * WAVE] = make_uint2(g_base, g_bits);
+                        else if ((uint32_t)(sp - RT_WF8_LDS_STACK) < wb.ovf_entries) ovf[(sp - RT_WF8_LDS_STACK) * WAVE] = make_uint2(g_base, g_bits);
+                        else atomicOr(&wb.totals[WF_TOTAL_ERROR], 2ull); // a tree deeper than its reported depth: never written past the allocation, the frame is discarded
                         sp++;
                     }
                     g_base = cb;
@@ -341,7 +348,8 @@ __global__ __launch_bounds__(WAVE, RT_WF8_MIN_WAVES) void k_wf_trace(DevScene sc
                             t_bits = nt | (lm << 8);
                         } else {
                             if (sp < RT_WF8_LDS_STACK) stack[sp * WAVE] = make_uint2(tb | WF8_KIND_T, nt | (lm << 8));
-                            else ovf[(sp - RT_WF8_LDS_STACK) * WAVE] = make_uint2(tb | WF8_KIND_T, nt | (lm << 8));
+                            else if ((uint32_t)(sp - RT_WF8_LDS_STACK) < wb.ovf_entries) ovf[(sp - RT_WF8_LDS_STACK) * WAVE] = make_uint2(tb | WF8_KIND_T, nt | (lm << 8));
+                            else atomicOr(&wb.totals[WF_TOTAL_ERROR], 2ull);
                             sp++;
                         }
                     }
@@ -360,6 +368,7 @@ __global__ __launch_bounds__(WAVE, RT_WF8_MIN_WAVES) void k_wf_trace(DevScene sc
                         sp = 0;
                     }
                     trips = cnt.tris - before;
+                    if (COUNT && wb.probe && !ANY && !second) cnt.tris = before;
                 }
                 if (COUNT) {
                     d_leaf_steps++;
@@ -368,8 +377,17 @@ __global__ __launch_bounds__(WAVE, RT_WF8_MIN_WAVES) void k_wf_trace(DevScene sc
                     d_leaf_trips += trips;
                 }
             }
-            const uint32_t busy = ((g_bits | t_bits) & 0xFFu) | (uint32_t)sp | (cur + 1u); // 0: nothing left to visit (and 0 on idle lanes)
+            uint32_t busy = ((g_bits | t_bits) & 0xFFu) | (uint32_t)sp | (cur + 1u); // 0: nothing left to visit (and 0 on idle lanes)
+            if (COUNT && !ANY && wb.probe && active && busy == 0u && !second) { // (development probe) walk the segment again, knowing where it ends
+                second = true;
+                hit.t = fminf(hit.t * 1.00001f, RT_F32_MAX);
+                hit.prim = RT_PRIM_MISS;
+                g_base = 0;
+                g_bits = sc.n_nodes ? (1u | (1u << 8)) : 0u;
+                busy = g_bits & 0xFFu;
+            }
             if (active && busy == 0u) { // segment finished
+                second = false;
                 if (ANY) {
                     if (hit.prim == RT_PRIM_MISS) atomicOr(reinterpret_cast<uint32_t*>(&wb.vtx[2 * (size_t)id + 1]) + 3, 1u << li);
                 } else {
@@ -396,6 +414,11 @@ __global__ __launch_bounds__(WAVE, RT_WF8_MIN_WAVES) void k_wf_trace(DevScene sc
             atomicAdd(&wb.totals[10], (unsigned long long)d_leaf_lanes);
             atomicAdd(&wb.totals[11], (unsigned long long)d_leaf_trips);
             atomicAdd(&wb.totals[12], (unsigned long long)d_refills);
+        }
+        const unsigned long long e0 = wave_sum(d_empty), e1 = wave_sum(d_entered);
+        if (lane == 0) {
+            atomicAdd(&wb.totals[6], e0);
+            atomicAdd(&wb.totals[7], e1);
         }
     }
 }
@@ -711,6 +734,22 @@ __global__ __launch_bounds__(256, RT_WF_SHADE_WAVES) void k_wf_shade(DevScene sc
     if ((threadIdx.x & 63u) == 0 && ns) atomicAdd(&wb.totals[2], ns);
 }
 
+// End of a bounce iteration: queue sizes move on, cursors are reset.  Round 3: run by the LAST block of k_wf_finish to end instead of a
+// one-thread kernel of its own (one launch less per bounce).  Every block's appends to the next queue (atomics on
+// WF_EXT_NEXT) precede its increment of WF_FINISH_DONE, so the block that sees the full count sees the final lengths; nothing else
+// runs on these counters until the next kernel of the stream.
+__device__ __forceinline__ void wf_advance(uint32_t* c) {
+    c[rt::WF_EXT_COUNT] = atomicAdd(&c[rt::WF_EXT_NEXT], 0u);
+    c[rt::WF_EXT_WINDOW] = c[rt::WF_EXT_WINDOW_NEXT];
+    c[rt::WF_EXT_NEXT] = 0;
+    c[rt::WF_SHADOW_COUNT] = 0;
+    c[rt::WF_SHADOW2_COUNT] = 0;
+    c[rt::WF_SHADOW2_CURSOR] = 0;
+    c[rt::WF_EXT_CURSOR] = 0;
+    c[rt::WF_SHADOW_CURSOR] = 0;
+    c[rt::WF_FINISH_DONE] = 0;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // shading stage 2: ordered light sum, terminal shading or continuation
 // ---------------------------------------------------------------------------------------------------------
@@ -849,20 +888,11 @@ __global__ __launch_bounds__(256, RT_WF_SHADE_WAVES) void k_wf_finish(DevScene s
     window_close(next_queue, win);
     const unsigned long long nc = wave_sum(n_cont);
     if ((threadIdx.x & 63u) == 0 && nc) atomicAdd(&wb.totals[1], nc);
-}
-
-__global__ void k_wf_advance(rt::WfBuffers wb, uint32_t iteration) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    uint32_t* c = wb.counters;
-    (void)iteration; // segment totals are tallied by the producing kernels (queue lengths include window padding)
-    c[rt::WF_EXT_COUNT] = c[rt::WF_EXT_NEXT];
-    c[rt::WF_EXT_WINDOW] = c[rt::WF_EXT_WINDOW_NEXT];
-    c[rt::WF_EXT_NEXT] = 0;
-    c[rt::WF_SHADOW_COUNT] = 0;
-    c[rt::WF_SHADOW2_COUNT] = 0;
-    c[rt::WF_SHADOW2_CURSOR] = 0;
-    c[rt::WF_EXT_CURSOR] = 0;
-    c[rt::WF_SHADOW_CURSOR] = 0;
+    __syncthreads(); // (every wave of the block has made its last reservation)
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&wb.counters[rt::WF_FINISH_DONE], 1u) == gridDim.x - 1u) wf_advance(wb.counters);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -962,8 +992,7 @@ hipError_t wf_bounce(const DevScene& sc, const DevFrame& fr, const WfBuffers& wb
         } else if (counters) launch_trace<true, true>(sc, wb, wb.q_shadow, WF_SHADOW_COUNT, WF_SHADOW_CURSOR, WF_SHADOW_WINDOW, s);
         else launch_trace<false, true>(sc, wb, wb.q_shadow, WF_SHADOW_COUNT, WF_SHADOW_CURSOR, WF_SHADOW_WINDOW, s);
     }
-    hipLaunchKernelGGL(k_wf_finish, sgrid, sblock, 0, s, sc, fr, wb, (const uint32_t*)cur_q, next_q);
-    hipLaunchKernelGGL(k_wf_advance, dim3(1), dim3(1), 0, s, wb, iteration);
+    hipLaunchKernelGGL(k_wf_finish, sgrid, sblock, 0, s, sc, fr, wb, (const uint32_t*)cur_q, next_q); // (its last block advances the queues)
     return hipGetLastError();
 }
 

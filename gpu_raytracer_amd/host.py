@@ -11,7 +11,7 @@ from . import types as T
 HOST_SYMBOLS = ["rt_host_material_new", "rt_host_light_new", "rt_host_push_constants_new", "rt_host_tile_count",
                 "rt_host_tiles_per_frame", "rt_host_default_scene", "rt_host_bvh_build", "rt_host_pack_scene_metadata",
                 "rt_host_render_progressive", "rt_host_branchless_float_if_nonnan", "rt_host_branchless_float_if",
-                "rt_host_branchless_u32_if", "rt_host_bvh_triangle"]
+                "rt_host_branchless_u32_if", "rt_host_bvh_triangle", "rt_host_triangle_aabb"]
 
 
 def _lib():
@@ -92,6 +92,19 @@ def bvh_triangle(triangle, vertices):
     if rc != 0:
         raise ValueError(f"rt_host_bvh_triangle failed: {rc}")
     return c, box
+
+
+def triangle_aabb(triangle, vertices):
+    """BvhBuilder::triangle_aabb (src/bvh.rs:272-275) -> aabb record"""
+    lib = _lib()
+    lib.rt_host_triangle_aabb.restype = C.c_int
+    tri = np.ascontiguousarray(triangle, dtype=T.TRIANGLE).reshape(())
+    ve = np.ascontiguousarray(vertices, dtype=T.VERTEX)
+    box = np.zeros((), dtype=T.AABB)
+    rc = lib.rt_host_triangle_aabb(C.c_void_p(tri.ctypes.data), _p(ve), C.c_uint32(len(ve)), C.c_void_p(box.ctypes.data))
+    if rc != 0:
+        raise ValueError(f"rt_host_triangle_aabb failed: {rc}")
+    return box
 
 
 def tile_count(width, height, tile_size=T.TILE_SIZE):

@@ -67,8 +67,11 @@ STATS = np.dtype([
     ("node_bytes", np.uint64), ("tri_bytes", np.uint64), ("scene_bytes", np.uint64),
     ("bvh_nodes", u32), ("bvh_depth", u32), ("n_devices", u32), ("flags", u32),
     ("texture_bytes", np.uint64), ("n_textures", u32), ("_pad", u32),
+    ("grid_bytes", np.uint64), ("grid_build_ms", np.float64),
 ])
 STAT_MEGAKERNEL_FALLBACK = 1
+STAT_SINGLE_PASS = 2
+PREPARE_SHADOW_GRIDS = 1
 MAX_BOUNCES = 255
 
 EXPECTED_SIZES = {

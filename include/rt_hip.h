@@ -62,6 +62,9 @@ extern "C" {
 #define RT_FLAG_NO_SHADOW_GRID 16u /* extended mode only: every shadow segment walks the BVH instead of its  */
                               /* light's triangle lists (A/B measurements and tests; same results)      */
 
+#define RT_FLAG_KERNEL_PIPELINE 32u /* extended mode only: always the queue pipeline, also for the frames that take the one-pass kernel */
+                              /* by rule (max_bounces 0 over a tiny tree; tests and A/B measurements; same results)        */
+
 typedef struct rt_ctx rt_ctx;
 
 typedef struct rt_render_params {
@@ -100,12 +103,18 @@ typedef struct rt_stats {
     uint64_t texture_bytes; /* bytes of texture data last handed to rt_upload_textures (never sampled) */
     uint32_t n_textures;   /* TextureInfo records last handed to rt_upload_textures                   */
     uint32_t _pad;
+    uint64_t grid_bytes;   /* device bytes of the per-light triangle lists ("light grids") of the extended mode's shadow stage;   */
+                           /* 0 until an extended-mode frame (or rt_prepare) has built them: rt_upload_scene* builds none          */
+    double grid_build_ms;  /* host wall time that build took (once per uploaded scene)                                            */
 } rt_stats;
 
 /* rt_stats.flags */
 #define RT_STAT_MEGAKERNEL_FALLBACK 1u /* extended mode: the frame did not fit the queue pipeline (more than 32 lights: one
                                           visibility bit per light; or a device share beyond the addressable path slots) and
                                           was rendered by the state-machine megakernel: same image, about 3x slower */
+
+#define RT_STAT_SINGLE_PASS 2u /* extended mode: primary rays only (max_bounces 0) over a tiny tree: rendered by the one-pass kernel that
+                                  keeps a pixel's samples in registers and stores it once (same image as the pipeline, several times faster) */
 
 #define RT_MAX_BOUNCES 255u /* extended mode: bounce depths travel in 8 bits, as in pack_flags (shared/src/lib.rs:1154-1179) */
 
@@ -147,6 +156,13 @@ int rt_upload_scene_packed(rt_ctx* ctx,
  * else: a host that keeps its update_* call sequence maps one to one.  Independent of rt_upload_scene*. */
 int rt_upload_textures(rt_ctx* ctx, const rt_texture_info* textures, uint32_t n_textures,
                        const uint8_t* texture_data, size_t n_bytes);
+
+/* Optional: pay now what rt_render would otherwise pay on the first frame that needs it.  RT_PREPARE_SHADOW_GRIDS: the per-light
+ * triangle lists of the extended mode's shadow stage (rt_stats.grid_bytes / grid_build_ms; 45-50 ms and 7.5 GB for a 262k-triangle
+ * scene with five lights).  A host that only renders the reference's modes 0/1 (src/compute.rs:12-50) never calls this and never
+ * pays: rt_upload_scene* builds only the tree.  No reference counterpart (the reference traces no shadow segments). */
+#define RT_PREPARE_SHADOW_GRIDS 1u
+int rt_prepare(rt_ctx* ctx, uint32_t what);
 
 /* Render a whole frame (all tiles of this context's share, all three colour channels in
  * one pass).  Replaces ComputeRenderer::run_compute's tile x channel loop

@@ -43,6 +43,8 @@ uint32_t rt_host_branchless_u32_if(int condition, uint32_t if_true, uint32_t if_
 
 /* BvhTriangle::centroid (src/bvh.rs:27-37) and BvhTriangleWithVertices::aabb (src/bvh.rs:47-55) of one triangle. */
 int rt_host_bvh_triangle(const rt_triangle* triangle, const rt_vertex* vertices, uint32_t n_vertices, float centroid[3], rt_aabb* box);
+/* BvhBuilder::triangle_aabb (src/bvh.rs:272-275): the per-triangle box the chunked build unions (:165). */
+int rt_host_triangle_aabb(const rt_triangle* triangle, const rt_vertex* vertices, uint32_t n_vertices, rt_aabb* box);
 
 /* SceneBuilder::build_default_scene (shared/src/lib.rs:1242-1286) + Camera::new.  Arrays must hold
  * 6 spheres, 2 triangles, 6 vertices, 4 materials, 1 light; returns 0, or -1 if a capacity is too small. */

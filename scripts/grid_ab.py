@@ -9,6 +9,7 @@ sc = scenes.SCENES[name]()
 with api.Context() as ctx:
     t0 = time.time(); ctx.upload_scene(sc); print(f"{name}: upload {1e3 * (time.time() - t0):.0f} ms", flush=True)
     t0 = time.time(); ctx.upload_scene(sc); print(f"{name}: second upload {1e3 * (time.time() - t0):.0f} ms", flush=True)
+    t0 = time.time(); ctx.prepare(); print(f"{name}: light grids {1e3 * (time.time() - t0):.0f} ms", flush=True)
     print("grids:", ctx.debug_shadow_grid())
     for li in range(len(sc.lights)): print("  light", li, ctx.debug_shadow_grid(li))
     crc = {}

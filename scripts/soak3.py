@@ -38,6 +38,8 @@ with api.Context() as ctx:
             else: lights.append(H.light_directional(tuple(b - a if np.linalg.norm(b - a) > 0 else (0, -1, 0)), (1, 1, 1), 0.7))         # along a triangle's edge: in its plane
         sc = scenes.Scene(sc.name, sc.spheres, np.array(lights, dtype=T.LIGHT), sc.vertices, sc.triangles, sc.materials, sc.camera)
         ctx.upload_scene(sc)
+        ctx.prepare()
+    ctx.prepare()
         g = ctx.debug_shadow_grid()
         with_grid += g["lights_with_grid"]
         for _ in range(3):

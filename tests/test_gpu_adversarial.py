@@ -4,6 +4,7 @@ the stack, the queue machinery — while the arithmetic that decides hits and co
 oracle's brute-force path (reference semantics) and to the CPU statement of the extended mode.
 """
 import dataclasses
+import os
 
 import numpy as np
 import pytest
@@ -135,6 +136,28 @@ def test_deep_degenerate_tree(gpu_ctx, oracle_mod):
     scene = _scene("degenerate_tree", np.concatenate([tris, same]), list(rng.integers(0, 4, n + 2000)))
     ref = _check(gpu_ctx, oracle_mod, scene, 120, 80, extended=(2, 2))
     assert (ref["prim"] != 0xFFFFFFFF).any()
+
+
+def test_box_areas_beyond_f32(gpu_ctx, oracle_mod):
+    """Finite coordinates of ~1e19: every box area overflows f32, so every cost of the collapse program is inf or NaN and no
+    comparison in it succeeds (k_db_merge then read its split tables at index -1).  The rule for that case is explicit
+    now (bvh_builder.cpp collapse8 / device_build.hip k_db_merge: a leaf only when the count allows it, else a 1 : 7 split): the tree
+    is poor but valid - every triangle in exactly one leaf - and the frames are the oracle's, with both builders."""
+    rng = np.random.default_rng(19)
+    n = 3000  # >= 1024: the device build
+    c = rng.uniform(-1.0, 1.0, (n, 1, 3)) * 4e19
+    tris = c + rng.uniform(-1.0, 1.0, (n, 3, 3)) * 6e18
+    cam = H.camera(position=(0.0, 0.0, 2.0e20), direction=(0.0, 0.0, -1.0), fov=30.0)
+    scene = _scene("areas_beyond_f32", tris, list(rng.integers(0, 4, n)), camera=cam)
+    assert np.isfinite(scene.vertices["position"]).all()
+    for method in ("2", "0"):
+        os.environ["RT_BUILD_METHOD"] = method
+        try:
+            ref = _check(gpu_ctx, oracle_mod, scene, 96, 64, camera=cam, extended=(2, 2))
+        finally:
+            del os.environ["RT_BUILD_METHOD"]
+        b = gpu_ctx.debug_check_bvh()
+        assert b["failures"] == 0 and b["placed_once"] == n and b["real_depth"] <= b["depth"], b
 
 
 def test_glass_with_unit_ior_and_total_internal_reflection(gpu_ctx, oracle_mod):

@@ -11,10 +11,15 @@ coordinates in the full frame).  Beyond that the size-independent properties: de
 accounting, and that a pixel does not depend on how the tiles are partitioned (src/compute.rs:194-209 tile geometry).
 Tolerance of the stated gate: |d rgb| <= 2e-3 for >= 99.9 % of pixels; asserted here: identical bits.
 """
+import os
+import sys
+import zlib
+
 import numpy as np
 import pytest
 
 from gpu_raytracer_amd import scenes
+from gpu_raytracer_amd import types as T
 
 pytestmark = pytest.mark.gpu
 
@@ -64,13 +69,54 @@ def test_cornell_1080p_64spp_primary_only_full_frame_vs_oracle(gpu_ctx, oracle_m
     ref = oracle_mod.render_extended(packed, w, h, spp, 0, flags=oracle_mod.EXT_NO_SHADOWS)
     st = gpu_ctx.render(w, h, scene.camera, mode=2, spp=spp, max_bounces=0, no_shadows=True, tile_size=TILE)
     assert (st["primary_rays"], st["continuation_rays"], st["shadow_rays"]) == (w * h * spp, 0, 0) and ref["segments"]["camera"] == w * h * spp
+    # primary rays only over a 12-triangle tree: the one-pass kernel (samples in registers, one store per pixel) by rule, round 3
+    assert st["flags"] & T.STAT_SINGLE_PASS and not st["flags"] & T.STAT_MEGAKERNEL_FALLBACK
+    np.testing.assert_array_equal(_bits(gpu_ctx.read_rgb32f()), _bits(ref["rgb"]))
+    # ... and the queue pipeline, which RT_FLAG_KERNEL_PIPELINE keeps, gives the same frame
+    st = gpu_ctx.render(w, h, scene.camera, mode=2, spp=spp, max_bounces=0, no_shadows=True, tile_size=TILE, kernel_pipeline=True)
+    assert not st["flags"] & T.STAT_SINGLE_PASS and (st["primary_rays"], st["shadow_rays"]) == (w * h * spp, 0)
     np.testing.assert_array_equal(_bits(gpu_ctx.read_rgb32f()), _bits(ref["rgb"]))
     # with the shadow segment toward the one light: the centre 640x360 of the frame on the CPU, the whole frame on the GPU
-    st = gpu_ctx.render(w, h, scene.camera, mode=2, spp=spp, max_bounces=0, tile_size=TILE)
-    assert st["primary_rays"] == w * h * spp and 0 < st["shadow_rays"] < st["primary_rays"]
     x0, y0, rw, rh = 640, 360, 640, 360
     ref = oracle_mod.render_extended(packed, w, h, spp, 0, region=(x0, y0, rw, rh))
-    np.testing.assert_array_equal(_bits(gpu_ctx.read_rgb32f()[y0:y0 + rh, x0:x0 + rw]), _bits(ref["rgb"]))
+    frames = []
+    for pipeline in (False, True):
+        st = gpu_ctx.render(w, h, scene.camera, mode=2, spp=spp, max_bounces=0, tile_size=TILE, kernel_pipeline=pipeline)
+        assert bool(st["flags"] & T.STAT_SINGLE_PASS) == (not pipeline)
+        assert st["primary_rays"] == w * h * spp and 0 < st["shadow_rays"] < st["primary_rays"]
+        frames.append((_bits(gpu_ctx.read_rgb32f()).copy(), st["shadow_rays"]))
+        np.testing.assert_array_equal(frames[-1][0][y0:y0 + rh, x0:x0 + rw], _bits(ref["rgb"]))
+    np.testing.assert_array_equal(frames[0][0], frames[1][0])
+    assert frames[0][1] == frames[1][1]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the headline configuration itself (BASELINE.json metric; configs[2]'s scene at 64 spp): sponza-like 1920x1080, 64 spp, 4 bounces
+# ---------------------------------------------------------------------------------------------------------
+def test_sponza_1080p_64spp_4_bounces_headline_frame_vs_oracle(gpu_ctx, oracle_mod):
+    """The frame every bench.py number is quoted on, rendered as bench.py renders it (32-pixel tiles): its CRC is the one bench.py
+    prints and expects, and crops of it - a corner at each end, the image centre, the neighbourhood of the grazed-edge pixel - carry
+    the CPU statement's bits (oracle_render_extended_region: a pixel's samples depend only on its coordinates in the full frame).
+    Pixel (844, 563) is the one place where the reference's own two paths disagree (tests/test_oracle_extended.py): the HIP path
+    gives its brute-force value there, the reference-format BVH walk of the oracle the other one."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    scene = scenes.sponza_like()
+    w, h, spp, bounces = 1920, 1080, 64, 4
+    gpu_ctx.upload_scene(scene)
+    st = gpu_ctx.render(w, h, scene.camera, mode=2, spp=spp, max_bounces=bounces, tile_size=TILE)
+    a = gpu_ctx.read_rgb32f()
+    assert st["primary_rays"] == w * h * spp and st["rays"] == st["primary_rays"] + st["continuation_rays"] + st["shadow_rays"]
+    assert zlib.crc32(a.tobytes()) & 0xFFFFFFFF == bench.HEADLINE_FRAME_CRC == 4012668657
+    packed = oracle_mod.PackedScene(scene)  # the reference-format chunked BVH (> 100k triangles), walked as shader/src/bvh.rs does
+    for (x0, y0, rw, rh) in ((0, 0, 6, 4), (957, 538, 6, 4), (w - 6, h - 4, 6, 4), (842, 562, 5, 3)):
+        ref = oracle_mod.render_extended(packed, w, h, spp, bounces, region=(x0, y0, rw, rh))["rgb"]
+        got = a[y0:y0 + rh, x0:x0 + rw]
+        differ = np.argwhere((_bits(got) != _bits(ref)).any(axis=-1))
+        expected = [[563 - y0, 844 - x0]] if (x0 <= 844 < x0 + rw and y0 <= 563 < y0 + rh) else []
+        assert differ.tolist() == expected, (x0, y0, differ.tolist())
+    # the grazed-edge pixel: the brute-force path's value (pinned against the oracle's brute-force walk in tests/test_oracle_extended.py)
+    assert _bits(a[563, 844]).tolist() == [1066366301, 1057316370, 1044521191]
 
 
 # ---------------------------------------------------------------------------------------------------------

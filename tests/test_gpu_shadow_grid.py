@@ -20,7 +20,10 @@ pytestmark = pytest.mark.gpu
 def _same_frame(ctx, scene, w, h, spp, bounces, min_answered=0.5, camera=None, expect_grids=None):
     cam = scene.camera if camera is None else camera
     ctx.upload_scene(scene)
+    assert ctx.debug_shadow_grid()["lights_with_grid"] == 0 and ctx.stats()["grid_bytes"] == 0  # uploads build no grids (round 3) ...
+    ctx.prepare()                                                                               # ... rt_prepare, or the first frame that needs them, does
     info = ctx.debug_shadow_grid()
+    assert ctx.stats()["grid_bytes"] == info["bytes"]
     if expect_grids is not None:
         assert info["lights_with_grid"] == expect_grids, (scene.name, info, [ctx.debug_shadow_grid(i) for i in range(len(scene.lights))])
     st = ctx.render(w, h, cam, mode=2, spp=spp, max_bounces=bounces, frame_seed=5, no_shadow_grid=True)

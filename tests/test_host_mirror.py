@@ -246,3 +246,13 @@ def test_bvh_triangle_bounding_box():  # src/bvh.rs:405-422: BvhTriangleWithVert
     with pytest.raises(ValueError):
         t["v2_index"] = 3
         host.bvh_triangle(t, v)
+
+
+def test_triangle_aabb():  # src/bvh.rs:510-523: BvhBuilder::triangle_aabb, the reference's own numbers (the 17th of its 17 unit tests)
+    t, v = _tri_verts([[0, 0, 0], [2, 0, 0], [1, 3, 0]])
+    box = host.triangle_aabb(t, v)
+    np.testing.assert_array_equal(box["min"], np.array([0, 0, 0], np.float32))
+    np.testing.assert_array_equal(box["max"], np.array([2, 3, 0], np.float32))
+    with pytest.raises(ValueError):
+        t["v0_index"] = 7
+        host.triangle_aabb(t, v)
