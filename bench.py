@@ -323,10 +323,14 @@ def main():
     # SURVEY §8e gather, outside the timed region: D2H of this rank's tiles, then one shared host framebuffer
     barrier_sync(dist, torch.cuda)
     g0 = time.perf_counter()
-    crc, _img = assemble_frame(dist, rank, n_gpus, ctx.read_rgb32f(), args.width, args.height, tile)
+    local_frame = ctx.read_rgb32f()  # device epilogue (pack to rgb32f) + D2H through pinned staging + the copy into the caller's array
+    d2h_ms = max_over_ranks(dist, (time.perf_counter() - g0) * 1e3, dev)
+    g1 = time.perf_counter()
+    crc, _img = assemble_frame(dist, rank, n_gpus, local_frame, args.width, args.height, tile)
     if part_world != n_gpus:
         crc = None  # a share of the frame, not the frame
-    gather_ms = max_over_ranks(dist, (time.perf_counter() - g0) * 1e3, dev)
+    crc_ms = max_over_ranks(dist, (time.perf_counter() - g1) * 1e3, dev)  # shared-framebuffer copies (N > 1) + zlib.crc32 over the float image on rank 0
+    gather_ms = d2h_ms + crc_ms
 
     # exact node / triangle fetch counts and wave-level step statistics from the counting variant of the same kernels
     # the same frame on one lane (RT_WF_LANES=1: every stage kernel alone on the chip) - what the rocprofv3 summaries under profiles/ time
@@ -422,7 +426,8 @@ def main():
                        "paths_per_s": total_seg[0] / dt,
                        "segments_per_step": {"camera": total_seg[0] / args.steps, "continuation": total_seg[1] / args.steps, "shadow": total_seg[2] / args.steps},
                        "kernel_mrays_per_s_rank0": ext_segments / avg_kernel_ms / 1e3,
-                       "frame_crc": crc, "frame_crc_expected": HEADLINE_FRAME_CRC if headline else None, "gather_ms": gather_ms,
+                       "frame_crc": crc, "frame_crc_expected": HEADLINE_FRAME_CRC if headline else None,
+                       "gather_ms": gather_ms, "d2h_ms": d2h_ms, "crc_ms": crc_ms,
                        "megakernel_fallback": bool(stc.get("flags", 0) & 1)},
             "roofline": roofline,
         }

@@ -23,6 +23,7 @@ FLAG_KERNEL_V1 = 4
 FLAG_KERNEL_SM = 8
 FLAG_NO_SHADOW_GRID = 16
 FLAG_KERNEL_PIPELINE = 32
+FLAG_NO_BEAMS = 64
 PREPARE_SHADOW_GRIDS = 1
 EXTENDED_AVAILABLE = True
 
@@ -135,12 +136,12 @@ class Context:
 
     # -- rendering -------------------------------------------------------------------
     def render(self, width, height, camera, mode=MODE_LEGACY, spp=1, max_bounces=4, frame_seed=0, tile_size=0,
-               tile_rank=0, tile_world=1, counters=False, no_shadows=False, kernel_v1=False, kernel_sm=False, no_shadow_grid=False, kernel_pipeline=False):
+               tile_rank=0, tile_world=1, counters=False, no_shadows=False, kernel_v1=False, kernel_sm=False, no_shadow_grid=False, kernel_pipeline=False, no_beams=False):
         p = np.zeros((), dtype=T.RENDER_PARAMS)
         p["camera"] = camera
         p["width"], p["height"], p["spp"], p["max_bounces"], p["mode"] = width, height, spp, max_bounces, mode
         p["frame_seed"], p["tile_size"], p["tile_rank"], p["tile_world"] = frame_seed, tile_size, tile_rank, tile_world
-        p["flags"] = (FLAG_COUNTERS if counters else 0) | (FLAG_NO_SHADOWS if no_shadows else 0) | (FLAG_KERNEL_V1 if kernel_v1 else 0) | (FLAG_KERNEL_SM if kernel_sm else 0) | (FLAG_NO_SHADOW_GRID if no_shadow_grid else 0) | (FLAG_KERNEL_PIPELINE if kernel_pipeline else 0)
+        p["flags"] = (FLAG_COUNTERS if counters else 0) | (FLAG_NO_SHADOWS if no_shadows else 0) | (FLAG_KERNEL_V1 if kernel_v1 else 0) | (FLAG_KERNEL_SM if kernel_sm else 0) | (FLAG_NO_SHADOW_GRID if no_shadow_grid else 0) | (FLAG_KERNEL_PIPELINE if kernel_pipeline else 0) | (FLAG_NO_BEAMS if no_beams else 0)
         self._check(self.lib.rt_render(self._h, _p(p)))
         self.width, self.height = width, height
         return self.stats()
@@ -172,6 +173,14 @@ class Context:
         t = np.zeros((self.height, self.width), np.float32)
         self._check(self.lib.rt_read_hits(self._h, _p(prim), _p(t), C.c_size_t(prim.size)))
         return prim, t
+
+    def debug_beams(self, n_blocks):
+        """Development aid: per owned 8x8 pixel block the length of its camera-beam triangle list (0xFFFFFFFF: none)."""
+        out = np.zeros(n_blocks, np.uint32)
+        m = self.lib.rt_debug_beams(self._h, _p(out), C.c_uint32(n_blocks))
+        if m < 0:
+            raise RtError(m, "rt_debug_beams")
+        return out[:m]
 
     def debug_counters(self):
         out = (C.c_ulonglong * 8)()

@@ -66,6 +66,7 @@ struct DeviceState {
     bool used_two_lanes = false;
     uint32_t wf_lights = 0;
     uint32_t wf_spp = 0; // spp the current wavefront allocation was sized for
+    bool wf_beams_off = false; // this frame walks the tree for its camera segments too (RT_FLAG_NO_BEAMS)
     std::vector<void*> wf_allocs;
 };
 
@@ -534,6 +535,15 @@ int ensure_wavefront(rt_ctx* ctx, DeviceState& d, uint32_t n_blocks, uint32_t ba
     HIPCHK(ctx, alloc((void**)&w.totals, 16 * sizeof(unsigned long long)));
     if (lane == 0) HIPCHK(ctx, alloc((void**)&w.accum, (size_t)std::max(1u, n_blocks) * 64 * 16));
     else w.accum = d.wf.accum; // one running sum per pixel: the lanes' resolves are ordered by events
+    if (lane == 0) { // the camera beams of the frame: per block a leaf list, built once per frame and read by both lanes
+        HIPCHK(ctx, alloc((void**)&w.beam_count, ((size_t)std::max(1u, n_blocks) + 1) * 4));
+        HIPCHK(ctx, alloc((void**)&w.beam_ref, (size_t)std::max(1u, n_blocks) * RT_BEAM_CAP * 4));
+        HIPCHK(ctx, alloc((void**)&w.beam_dist, (size_t)std::max(1u, n_blocks) * RT_BEAM_CAP * 4));
+    } else {
+        w.beam_count = d.wf.beam_count;
+        w.beam_ref = d.wf.beam_ref;
+        w.beam_dist = d.wf.beam_dist;
+    }
     HIPCHK(ctx, alloc((void**)&w.stack_ovf, (size_t)rt::wf_persistent_waves() * ovf_entries * 64 * 8));
     w.ovf_entries = ovf_entries;
     w.n_blocks = n_blocks;
@@ -677,6 +687,12 @@ int run_frame(rt_ctx* ctx, DevFrame fr, bool counters, uint32_t world, uint32_t 
             if (rc != RT_OK) return rc;
             HIPCHK(ctx, hipMemsetAsync(d.wf.totals, 0, 16 * sizeof(unsigned long long), d.stream));
             HIPCHK(ctx, hipEventRecord(d.ev0, d.stream)); // re-record: allocation above is not part of the kernel time
+            { // camera beams: on by default, RT_WF_BEAMS=0 (development knob) or RT_FLAG_NO_BEAMS walks the tree for every camera segment
+                const char* be = std::getenv("RT_WF_BEAMS");
+                const bool beams = !(f.flags & RT_FLAG_NO_BEAMS) && (be ? std::atoi(be) != 0 : true);
+                d.wf_beams_off = !beams;
+                if (beams) HIPCHK(ctx, rt::wf_beams(scene_for(ctx, d), f, d.wf, d.stream));
+            }
             if (two) {
                 HIPCHK(ctx, hipEventRecord(d.ev_start, d.stream));
                 HIPCHK(ctx, hipStreamWaitEvent(d.stream2, d.ev_start, 0));
@@ -715,14 +731,15 @@ int run_frame(rt_ctx* ctx, DevFrame fr, bool counters, uint32_t world, uint32_t 
             HIPCHK(ctx, hipSetDevice(d.device));
             const uint32_t n = std::min(r.batch, r.f.spp - r.first);
             const uint32_t lane = r.two ? (r.j & 1u) : 0u;
-            rt::WfBuffers& w = lane ? d.wf2 : d.wf;
+            rt::WfBuffers w = lane ? d.wf2 : d.wf; // (a copy: the kernels take it by value)
+            if (d.wf_beams_off) w.beam_count = nullptr;
             hipStream_t st = lane ? d.stream2 : d.stream;
             if (r.phase == WfRun::GENERATE) {
                 HIPCHK(ctx, rt::wf_generate(r.dsc, r.f, w, r.first, n, st));
                 r.it = 0;
                 r.phase = WfRun::BOUNCE;
             } else if (r.phase == WfRun::BOUNCE) {
-                HIPCHK(ctx, rt::wf_bounce(r.dsc, r.f, w, r.it, counters, st));
+                HIPCHK(ctx, rt::wf_bounce(r.dsc, r.f, w, r.it, n, counters, st));
                 if (r.it >= r.f.max_bounce) r.phase = WfRun::RESOLVE;
                 else if ((r.it & 7u) == 7u) {
                     HIPCHK(ctx, hipMemcpyAsync(&r.alive, w.counters + rt::WF_EXT_COUNT, 4, hipMemcpyDeviceToHost, st));
@@ -1305,6 +1322,21 @@ int rt_read_hits(rt_ctx* ctx, uint32_t* prim_ids, float* t, size_t n_pixels) {
 // Development aid (not part of rt_hip.h): wave-level diagnostics of the last RT_FLAG_COUNTERS render of the
 // state-machine kernel: transition passes, lanes served, node iterations, lanes active, leaf iterations, lanes
 // active, cycles in transition phases, cycles in traversal phases (summed over waves).
+// Development aid: the camera beams of the last extended-mode frame on the first device: per owned 8x8 pixel block the length of its
+// triangle list (0xFFFFFFFF: no list).  Returns the number of blocks (<= n), negative on error.
+int rt_debug_beams(rt_ctx* ctx, uint32_t* counts, uint32_t n) {
+    if (!ctx || ctx->devs.empty()) return RT_ERR_BAD_ARG;
+    DeviceState& d = ctx->devs[0];
+    if (!d.wf.beam_count) return 0;
+    if (hipSetDevice(d.device) != hipSuccess) return RT_ERR_HIP;
+    (void)hipStreamSynchronize(d.stream);
+    const uint32_t m = std::min(n, d.wf.n_blocks);
+    if (m && hipMemcpy(counts, d.wf.beam_count, (size_t)m * 4, hipMemcpyDeviceToHost) != hipSuccess) return RT_ERR_HIP;
+    for (uint32_t i = 0; i < m; i++)
+        if (counts[i] & RT_BEAM_OVERFLOW) counts[i] = 0xFFFFFFFFu;
+    return (int)m;
+}
+
 int rt_debug_counters(rt_ctx* ctx, unsigned long long out[8]) {
     if (!ctx || !out) return RT_ERR_BAD_ARG;
     for (int k = 0; k < 8; k++) out[k] = ctx->diag[k];

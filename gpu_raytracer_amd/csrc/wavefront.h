@@ -30,7 +30,9 @@ enum WfCounter : uint32_t {
     WF_SHADOW2_CURSOR = 9,
     WF_SHADOW2_WINDOW = 10, // stays 0: the handed-on queue is written densely
     WF_FINISH_DONE = 11,    // blocks of k_wf_finish that have ended (the last one advances the queues)
-    WF_N_COUNTERS = 12
+    WF_FB_COUNT = 12,       // camera segments of pixel blocks without a beam list (they walk the tree): entries in q_ext[1] at depth 0, dense
+    WF_FB_CURSOR = 13,
+    WF_N_COUNTERS = 16
 };
 
 struct WfBuffers {
@@ -60,9 +62,16 @@ struct WfBuffers {
     uint32_t n_blocks;   // 8x8 pixel blocks owned by this device
     uint32_t batch;      // samples per pixel in flight
     uint32_t capacity;   // path slots
+    // camera beams (round 3): per owned 8x8 pixel block the leaves its frustum touches, nearest first; the camera segments of the block
+    // test them directly instead of walking the tree (k_wf_beams / k_wf_trace_camera).  Null: every camera segment walks the tree.
+    uint32_t* beam_count; // [n_blocks] triangles in the block's list, or RT_BEAM_OVERFLOW | j: no list (too many: its segments walk the tree); [n_blocks]: blocks without a list
+    uint32_t* beam_ref;   // [n_blocks][RT_BEAM_CAP] triangle records (index into DevScene::tris)
+    float* beam_dist;     // [n_blocks][RT_BEAM_CAP] a lower bound of the distance from the camera to the triangle, ascending
     uint32_t probe;      // development probes of the counting kernel variants (RT_WF_PROBE), 0 otherwise
 };
 
+#define RT_BEAM_CAP 128u /* triangles per block list; 98 % of the headline frame's blocks need fewer */
+#define RT_BEAM_OVERFLOW 0x80000000u /* beam_count[b]: this bit = no list; the low bits then number the blocks without a list (their place in the walk queue) */
 #define WF_TOTAL_ERROR 15 /* totals[] slot: non-zero = a queue reservation did not fit; every later stage kernel of the frame returns at once */
 #ifndef RT_WF8_LDS_STACK
 #define RT_WF8_LDS_STACK 8 /* 64-bit traversal stack entries per lane kept in LDS by the persistent kernels; deeper ones overflow to HBM */
@@ -75,8 +84,9 @@ size_t wf_queue_slots(size_t max_entries, uint32_t per_lane); // allocation boun
 size_t wf_queue_slots_for(size_t max_entries, uint32_t per_lane, size_t producing_waves); // the same for a given number of producing waves (host-only arithmetic, unit-tested)
 uint32_t wf_pick_window(uint32_t iterations, uint32_t per_lane); // the reservation window a producing wave uses (host copy of the device rule, unit-tested)
 uint32_t wf_persistent_waves(); // grid size (in 64-lane blocks) of the persistent traversal kernels on the current device
+hipError_t wf_beams(const DevScene& sc, const DevFrame& fr, const WfBuffers& wb, hipStream_t s); // once per frame and device, before the batches
 hipError_t wf_generate(const DevScene& sc, const DevFrame& fr, const WfBuffers& wb, uint32_t first_sample, uint32_t n_samples, hipStream_t s);
-hipError_t wf_bounce(const DevScene& sc, const DevFrame& fr, const WfBuffers& wb, uint32_t iteration, bool counters, hipStream_t s);
+hipError_t wf_bounce(const DevScene& sc, const DevFrame& fr, const WfBuffers& wb, uint32_t iteration, uint32_t n_samples, bool counters, hipStream_t s); // n_samples: samples per pixel in this batch (iteration 0)
 hipError_t wf_resolve(const DevFrame& fr, const WfBuffers& wb, const DevTargets& tg, uint32_t n_samples, bool first_batch, bool last_batch, hipStream_t s);
 
 } // namespace rt

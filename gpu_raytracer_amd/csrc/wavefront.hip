@@ -48,6 +48,7 @@ using namespace rtdev;
 namespace {
 
 __device__ __forceinline__ V3 f4v(float4 a) { return v3(a.x, a.y, a.z); }
+#define RT_KEEP4_EARLY(v) asm volatile("" : "+v"((v).x), "+v"((v).y), "+v"((v).z), "+v"((v).w))
 
 // Queue output through wave-private windows.  A single counter sustains ~90 M atomics/s (MI355X_MICROARCH.md,
 // "dequeue"): one atomic per wave-iteration made the shading stages atomic-bound, and so did fixed 512-slot
@@ -124,7 +125,10 @@ __global__ __launch_bounds__(256) void k_wf_generate(DevFrame fr, rt::WfBuffers 
     OutWindow win = {0u, 0u};
     uint32_t real = 0;
     const uint32_t window = pick_window((n_slots_blocks + n_waves - 1u) / n_waves, 1u);
-    if (blockIdx.x == 0 && threadIdx.x == 0) wb.counters[rt::WF_EXT_WINDOW] = window;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        wb.counters[rt::WF_EXT_WINDOW] = window;
+        if (wb.beam_count) wb.counters[rt::WF_FB_COUNT] = wb.beam_count[wb.n_blocks] * (n_slots_blocks / max(1u, wb.n_blocks)) * WAVE; // blocks without a list x samples x 64
+    }
     // path slot p = (b * n_samples + k) * 64 + lane: all samples of an 8x8 pixel block are neighbours in the queue, so
     // the segments in flight at any moment (queue order survives compaction) come from a small part of the image
     const uint32_t n_samples = n_slots_blocks / max(1u, wb.n_blocks);
@@ -160,6 +164,15 @@ __global__ __launch_bounds__(256) void k_wf_generate(DevFrame fr, rt::WfBuffers 
             const uint32_t at = window_reserve(wb.q_ext[0], &wb.counters[rt::WF_EXT_COUNT], win, window, mine, incl, total, wb.q_ext_cap, &wb.totals[WF_TOTAL_ERROR]);
             if (mine && at != WF_NO_SLOT) wb.q_ext[0][at] = p;
             real += mine;
+            // camera segments of a block without a beam list walk the tree in the persistent kernel: a second, dense queue in the buffer
+            // that becomes the next extension queue only after this depth's traversal (k_wf_finish writes it from position 0 then)
+        }
+        // camera segments of a block without a beam list walk the tree in the persistent kernel: a second queue, in the buffer that
+        // becomes the next extension queue only after this depth's traversal.  No atomics: the j-th block without a list owns the
+        // entries [(j n_samples + k) 64, + 64), lanes without a pixel leave a sentinel
+        if (wb.beam_count) {
+            const uint32_t bc = wb.beam_count[b];
+            if (bc & RT_BEAM_OVERFLOW) wb.q_ext[1][((size_t)(bc & ~RT_BEAM_OVERFLOW) * n_samples + k) * WAVE + lane] = px.valid ? p : WF_SENTINEL;
         }
     }
     window_close(wb.q_ext[0], win);
@@ -419,6 +432,292 @@ __global__ __launch_bounds__(WAVE, RT_WF8_MIN_WAVES) void k_wf_trace(DevScene sc
         if (lane == 0) {
             atomicAdd(&wb.totals[6], e0);
             atomicAdd(&wb.totals[7], e1);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Camera beams (round 3).  All camera segments leave one point, and the 64 samples x 64 pixels of an 8x8 pixel block leave it through
+// a pyramid a quarter of a degree wide: the leaves of the tree that pyramid touches are few (median 16 triangles, 98 % of the
+// headline frame's blocks under 128 leaves) and the same for every segment of the block.  k_wf_beams collects them once per frame -
+// a frustum walk of the 8-wide tree, one wave per block, eight nodes x eight child slots per step - and orders them by a lower
+// bound of their distance; k_wf_trace_camera then tests a block's segments against its list, nearest leaf first, every lane on the
+// same triangle (no stack, no divergence, full lanes), until the next leaf lies beyond every lane's hit.  This replaces the tree walk
+// (14 node visits x ~200 instructions at 74 % of the lanes) for a third of the closest-hit segments.  Same results: which triangle is
+// hit is decided by the same Moeller-Trumbore statement with the same tie rule (lowest triangle index among equal t), and the list is a
+// superset of the triangles that statement can accept for any segment of the block - the pyramid is widened by an eighth of a pixel
+// (600 x the rounding of a direction) and the leaf boxes by 2e-6 of their magnitude.  Blocks whose list would exceed RT_BEAM_CAP leaves
+// (views along a colonnade) or whose pyramid is degenerate (NaN cameras) keep the per-lane tree walk.
+// Replaces, for depth-0 segments, BvhTraverser::traverse_and_intersect (shader/src/bvh.rs:18-88).
+// ---------------------------------------------------------------------------------------------------------
+#ifndef RT_BEAM_STACK
+#define RT_BEAM_STACK 512
+#endif
+#ifndef RT_BEAM_LEAVES
+#define RT_BEAM_LEAVES 1024 /* leaves the frustum walk may collect before it gives up (their triangles are then tested one by one against the pyramid) */
+#endif
+#ifndef RT_BEAM_MARGIN_PX
+#define RT_BEAM_MARGIN_PX 0.125f
+#endif
+#ifndef RT_BEAM_DIST_SCALE
+#define RT_BEAM_DIST_SCALE 0.99999f
+#endif
+#ifndef RT_BEAM_EARLY_OUT
+#define RT_BEAM_EARLY_OUT 1
+#endif
+#ifndef RT_BEAM_TRI_CULL
+#define RT_BEAM_TRI_CULL 1
+#endif
+struct BeamPlanes {
+    V3 n[4]; // inward normals of the pyramid's four sides (through the camera position)
+    V3 o;
+};
+// is the box [lo, hi] (already padded) outside the pyramid?  The corner farthest along each plane's inward normal decides.
+__device__ __forceinline__ bool beam_outside(const BeamPlanes& bp, const float lo[3], const float hi[3]) {
+    bool outside = false;
+    for (int k = 0; k < 4; k++) {
+        const V3 pv = v3((bp.n[k].x > 0.0f ? hi[0] : lo[0]) - bp.o.x, (bp.n[k].y > 0.0f ? hi[1] : lo[1]) - bp.o.y, (bp.n[k].z > 0.0f ? hi[2] : lo[2]) - bp.o.z);
+        outside = outside || dot(bp.n[k], pv) < 0.0f;
+    }
+    return outside;
+}
+// a lower bound of the distance from the camera to anything inside the box (segment directions are unit vectors: t is a distance)
+__device__ __forceinline__ float beam_box_distance(const V3 o, const float lo[3], const float hi[3]) {
+    const float dx = fmaxf(fmaxf(lo[0] - o.x, o.x - hi[0]), 0.0f), dy = fmaxf(fmaxf(lo[1] - o.y, o.y - hi[1]), 0.0f), dz = fmaxf(fmaxf(lo[2] - o.z, o.z - hi[2]), 0.0f);
+    return sqrtf(dx * dx + dy * dy + dz * dz) * RT_BEAM_DIST_SCALE;
+}
+__global__ __launch_bounds__(WAVE) void k_wf_beams(DevScene sc, DevFrame fr, rt::WfBuffers wb) {
+    __shared__ uint32_t s_nodes[RT_BEAM_STACK];
+    __shared__ uint32_t s_leaf[RT_BEAM_LEAVES];
+    __shared__ uint32_t s_ref[RT_BEAM_CAP];
+    __shared__ float s_dist[RT_BEAM_CAP];
+    const uint32_t lane = threadIdx.x, b = blockIdx.x;
+    const PixelCoord p0 = block_pixel_at(fr, b, 0); // the block's first pixel (defined also when it lies outside the image)
+    const float x0 = (float)p0.x - RT_BEAM_MARGIN_PX, x1 = (float)p0.x + 8.0f + RT_BEAM_MARGIN_PX;
+    const float y0 = (float)p0.y - RT_BEAM_MARGIN_PX, y1 = (float)p0.y + 8.0f + RT_BEAM_MARGIN_PX;
+    const DevCamera& cam = fr.cam;
+    auto dir = [&](float sx, float sy) { // camera_ray's direction before it is normalised
+        const float u = sx / cam.width_f, v = sy / cam.height_f;
+        const float cx = (u * 2.0f - 1.0f) * cam.aspect * cam.fov_scale, cy = (1.0f - v * 2.0f) * cam.fov_scale;
+        return ld3(cam.forward) + ld3(cam.right) * cx + ld3(cam.true_up) * cy;
+    };
+    const V3 cs[4] = {dir(x0, y0), dir(x1, y0), dir(x1, y1), dir(x0, y1)};
+    const V3 cc = dir(0.5f * (x0 + x1), 0.5f * (y0 + y1));
+    BeamPlanes bp;
+    bp.o = ld3(cam.origin);
+    bool bad = false;
+    for (int k = 0; k < 4; k++) {
+        bp.n[k] = cross(cs[k], cs[(k + 1) & 3]);
+        const float s = dot(bp.n[k], cc);
+        if (s < 0.0f) bp.n[k] = -bp.n[k];
+        // the four corner directions must lie on the inner side of every plane (a pyramid narrower than 180 degrees, finite numbers)
+        for (int j = 0; j < 4; j++)
+            bad = bad || !(dot(bp.n[k], cs[j]) >= -1e-6f * (fabsf(bp.n[k].x) + fabsf(bp.n[k].y) + fabsf(bp.n[k].z)) * (fabsf(cs[j].x) + fabsf(cs[j].y) + fabsf(cs[j].z)));
+        bad = bad || !(fabsf(s) > 0.0f) || !(fabsf(s) < RT_F32_MAX);
+    }
+    uint32_t n_stack = 0, n_leaf = 0;
+    bool overflow = bad;
+    if (sc.n_nodes) {
+        if (lane == 0) s_nodes[0] = 0u;
+        n_stack = 1;
+    }
+    __syncthreads();
+    const uint32_t slot = lane & 7u;
+    const unsigned long long lower = (1ull << lane) - 1ull;
+    // ---- the frustum walk: eight nodes x eight child slots per step
+    while (n_stack > 0 && !overflow) {
+        const uint32_t take = min(n_stack, 8u), base = n_stack - take;
+        const bool have = (lane >> 3) < take;
+        const uint32_t node = have ? s_nodes[base + (lane >> 3)] : 0u;
+        __syncthreads(); // (the reads above precede the pushes below)
+        n_stack = base;
+        bool inner = false, leaf = false;
+        uint32_t ref = 0;
+        if (have) {
+            const DevNode8& nd = sc.nodes[node];
+            const uint32_t ex = nd.ex_imask, imask = ex >> 24, lmask = nd.lmask & 0xFFu;
+            if (((imask | lmask) >> slot) & 1u) {
+                float lo[3], hi[3];
+                for (int a = 0; a < 3; a++) {
+                    const float sca = ldexpf(1.0f, (int)(int8_t)((ex >> (8 * a)) & 0xFFu));
+                    const float ql = (float)((nd.qlo[a][slot >> 2] >> (8u * (slot & 3u))) & 0xFFu), qh = (float)((nd.qhi[a][slot >> 2] >> (8u * (slot & 3u))) & 0xFFu);
+                    lo[a] = nd.org[a] + ql * sca;
+                    hi[a] = nd.org[a] + qh * sca;
+                    const float pad = (fabsf(lo[a]) + fabsf(hi[a])) * 2.0e-6f + 1.0e-30f; // the rounding of the two sums above, and vertices an ulp outside their box (bvh_check.h)
+                    lo[a] -= pad;
+                    hi[a] += pad;
+                }
+                if (!beam_outside(bp, lo, hi)) {
+                    const uint32_t below = (1u << slot) - 1u;
+                    if ((imask >> slot) & 1u) {
+                        inner = true;
+                        ref = nd.child_base + (uint32_t)__popc(imask & below);
+                    } else {
+                        leaf = true;
+                        ref = nd.tri_base + RT_DEV_LEAF_STRIDE * (uint32_t)__popc(lmask & below);
+                    }
+                }
+            }
+        }
+        const unsigned long long mi = __ballot(inner), ml = __ballot(leaf);
+        const uint32_t pi = n_stack + (uint32_t)__popcll(mi & lower), pc = n_leaf + (uint32_t)__popcll(ml & lower);
+        if (inner && pi < RT_BEAM_STACK) s_nodes[pi] = ref;
+        if (leaf && pc < RT_BEAM_LEAVES) s_leaf[pc] = ref;
+        n_stack += (uint32_t)__popcll(mi);
+        n_leaf += (uint32_t)__popcll(ml);
+        overflow = n_stack > RT_BEAM_STACK || n_leaf > RT_BEAM_LEAVES;
+        __syncthreads();
+    }
+    // ---- the triangles of those leaves, each against the pyramid by its own box
+    uint32_t n_tri = 0;
+    for (uint32_t l0 = 0; l0 < n_leaf && !overflow; l0 += WAVE) {
+        const uint32_t li = l0 + lane;
+        uint32_t first = 0, count = 0;
+        if (li < n_leaf) {
+            first = s_leaf[li];
+            count = sc.tris[first].leaf_count;
+        }
+        for (uint32_t k = 0; k < RT_DEV_LEAF_STRIDE; k++) { // (wave-uniform trip count: the appends are wave operations)
+            bool keep = false;
+            float dist = 0.0f;
+            if (k < count) {
+                const DevTri& t = sc.tris[first + k];
+                float lo[3], hi[3];
+                for (int a = 0; a < 3; a++) {
+                    const float va = t.v0[a], vb = t.v0[a] + t.e1[a], vc = t.v0[a] + t.e2[a];
+                    lo[a] = fminf(va, fminf(vb, vc));
+                    hi[a] = fmaxf(va, fmaxf(vb, vc));
+                    const float pad = (fabsf(lo[a]) + fabsf(hi[a])) * 2.0e-6f + 1.0e-30f;
+                    lo[a] -= pad;
+                    hi[a] += pad;
+                }
+                keep = !RT_BEAM_TRI_CULL || !(lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2]) || !beam_outside(bp, lo, hi); // (non-finite boxes are kept: the test decides)
+                dist = beam_box_distance(bp.o, lo, hi);
+                if (!(dist >= 0.0f)) dist = 0.0f;
+            }
+            const unsigned long long mk = __ballot(keep);
+            const uint32_t pos = n_tri + (uint32_t)__popcll(mk & lower);
+            if (keep && pos < RT_BEAM_CAP) {
+                s_ref[pos] = first + k;
+                s_dist[pos] = dist;
+            }
+            n_tri += (uint32_t)__popcll(mk);
+        }
+        overflow = n_tri > RT_BEAM_CAP;
+    }
+    __syncthreads();
+    if (overflow) { // no list: the block's camera segments walk the tree; it takes the next place in the queue k_wf_generate fills for them
+        if (lane == 0) wb.beam_count[b] = RT_BEAM_OVERFLOW | atomicAdd(&wb.beam_count[wb.n_blocks], 1u);
+        return;
+    }
+    // nearest first: every entry finds its rank (ties by position)
+    for (uint32_t i = lane; i < n_tri; i += WAVE) {
+        const float di = s_dist[i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < n_tri; j++) {
+            const float dj = s_dist[j];
+            rank += (dj < di || (dj == di && j < i)) ? 1u : 0u;
+        }
+        wb.beam_ref[(size_t)b * RT_BEAM_CAP + rank] = s_ref[i];
+        wb.beam_dist[(size_t)b * RT_BEAM_CAP + rank] = di;
+    }
+    if (lane == 0) wb.beam_count[b] = n_tri;
+}
+
+// Depth-0 closest hits from the block lists.  One wave per pixel block: the list's triangle records are staged in LDS once and every
+// sample of the block's 64 pixels (path slots (b * n_samples + k) * 64 + lane, as k_wf_generate lays them out) is tested against them,
+// all lanes on the same triangle (broadcast LDS reads).  Blocks without a list are skipped: k_wf_generate put their segments on a
+// queue of their own for k_wf_trace.
+template <bool COUNT>
+__global__ __launch_bounds__(WAVE) void k_wf_trace_camera(DevScene sc, rt::WfBuffers wb, uint32_t n_samples) {
+    extern __shared__ uint4 s_cam[]; // RT_BEAM_CAP * 3 quads + RT_BEAM_CAP floats (+ a per-lane walk stack behind them for the development probe)
+    if (wb.totals[WF_TOTAL_ERROR] != 0ull) return;
+    const uint32_t lane = threadIdx.x;
+    float* s_d = reinterpret_cast<float*>(s_cam + RT_BEAM_CAP * 3u);
+    Counts cnt = {0u, 0u};
+    for (uint32_t b = blockIdx.x; b < wb.n_blocks; b += gridDim.x) {
+        const uint32_t k_first = 0u, k_end = n_samples;
+        const uint32_t n_list = (uint32_t)__builtin_amdgcn_readfirstlane((int)wb.beam_count[b]);
+        if (n_list & RT_BEAM_OVERFLOW) continue; // (k_wf_generate queues this block's segments for the tree walk)
+        {
+            __syncthreads(); // (the previous block's reads are done)
+            for (uint32_t i = lane; i < n_list; i += WAVE) {
+                const uint32_t slot = wb.beam_ref[(size_t)b * RT_BEAM_CAP + i];
+                const uint4* __restrict__ rec = reinterpret_cast<const uint4*>(sc.tris + slot);
+                const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+                s_cam[3u * i] = q0;
+                s_cam[3u * i + 1u] = q1;
+                s_cam[3u * i + 2u] = make_uint4(q2.x, q2.y, q2.z, slot); // (the leaf length of the record is not needed here: its place carries the record's index)
+                s_d[i] = wb.beam_dist[(size_t)b * RT_BEAM_CAP + i];
+            }
+            __syncthreads();
+        }
+        for (uint32_t k = k_first; k < k_end; k++) {
+            const uint32_t sb = RT_WF_BLOCK_MAJOR ? b * n_samples + k : k * wb.n_blocks + b;
+            const uint32_t p = sb * WAVE + lane;
+            const bool valid = wb.pxy[p] != 0xFFFFFFFFu;
+            if (__ballot(valid) == 0ull) continue;
+            V3 o = v3(0.0f, 0.0f, 0.0f), d = v3(0.0f, 0.0f, 1.0f);
+            if (valid) {
+                float4 ro = wb.ray_o[p], rd = wb.ray_d[p];
+                RT_KEEP4_EARLY(ro);
+                RT_KEEP4_EARLY(rd);
+                o = f4v(ro);
+                d = f4v(rd);
+            }
+            Hit hit;
+            hit.t = valid ? RT_F32_MAX : -1.0f; // (lanes without a path never ask for another triangle)
+            hit.prim = RT_PRIM_MISS;
+            hit.slot = 0;
+            if (valid) test_spheres(sc, o, d, hit);
+            {
+                for (uint32_t i = 0; i < n_list; i++) {
+                    if (RT_BEAM_EARLY_OUT && __ballot(s_d[i] < hit.t) == 0ull) break; // sorted: every later triangle is farther still
+                    const uint4 q0 = s_cam[3u * i], q1 = s_cam[3u * i + 1u], q2 = s_cam[3u * i + 2u];
+                    if (COUNT && valid) cnt.tris++;
+                    float t = 0.0f;
+                    const bool inside = moller_trumbore(v3(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z)), v3(__uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y)),
+                                                        v3(__uint_as_float(q1.z), __uint_as_float(q1.w), __uint_as_float(q2.x)), o, d, t);
+                    // the acceptance rule of test_triangle (device_common.h): lowest index among equal t, strict against a sphere.  Written as
+                    // selects under ONE mask: with the three assignments inside an `if`, hipcc (ROCm 7.2) kept the old record index on the lanes
+                    // accepted through the tie clause (found as 1 wrong pixel per 2 M segments; tests/test_gpu_beams.py holds the tie scene)
+                    const uint32_t prim = q2.z;
+                    const bool accept = inside && t > RT_MIN_RAY_DISTANCE && (t < hit.t || (t == hit.t && prim < hit.prim && hit.prim < RT_PRIM_SPHERE_FLAG));
+                    hit.t = accept ? t : hit.t;
+                    hit.prim = accept ? prim : hit.prim;
+                    hit.slot = accept ? q2.w : hit.slot;
+                }
+            }
+            if (COUNT && wb.probe == 2u && valid) { // development probe: the same segment by the tree walk (the launch provides the extra LDS)
+                Hit h2;
+                h2.t = RT_F32_MAX;
+                h2.prim = RT_PRIM_MISS;
+                h2.slot = 0;
+                Counts c2 = {0u, 0u};
+                test_spheres(sc, o, d, h2);
+                traverse<false, false>(sc, o, d, reinterpret_cast<uint2*>(s_cam + RT_BEAM_CAP * 4u) + lane, h2, c2);
+                if (h2.prim != hit.prim || h2.t != hit.t) {
+                    if (atomicAdd(&wb.totals[6], 1ull) == 0ull) {
+                        wb.totals[8] = b;
+                        wb.totals[9] = ((unsigned long long)hit.prim << 32) | h2.prim;
+                        wb.totals[10] = ((unsigned long long)__float_as_uint(hit.t) << 32) | __float_as_uint(h2.t);
+                        wb.totals[11] = ((unsigned long long)n_list << 32) | h2.slot;
+                        wb.totals[12] = p;
+                    }
+                }
+            }
+            if (valid) {
+                const V3 hp = o + d * hit.t;
+                const uint32_t code = hit.prim == RT_PRIM_MISS ? RT_PRIM_MISS : ((hit.prim & RT_PRIM_SPHERE_FLAG) ? hit.prim : hit.slot);
+                wb.hit[p] = make_uint4(__float_as_uint(hp.x), __float_as_uint(hp.y), __float_as_uint(hp.z), code);
+            }
+        }
+    }
+    if (COUNT) {
+        const unsigned long long n0 = wave_sum(cnt.nodes), n1 = wave_sum(cnt.tris);
+        if (lane == 0) {
+            atomicAdd(&wb.totals[3], n0);
+            atomicAdd(&wb.totals[4], n1);
         }
     }
 }
@@ -961,6 +1260,14 @@ size_t wf_queue_slots(size_t max_entries, uint32_t per_lane) { return wf_queue_s
 uint32_t wf_pick_window(uint32_t iters, uint32_t per_lane) { return pick_window(iters, per_lane); }
 uint32_t wf_persistent_waves() { return (uint32_t)(cu_count() * RT_WF_WAVES_PER_CU); }
 
+hipError_t wf_beams(const DevScene& sc, const DevFrame& fr, const WfBuffers& wb, hipStream_t s) {
+    if (!wb.beam_count || wb.n_blocks == 0) return hipSuccess;
+    const hipError_t e = hipMemsetAsync(wb.beam_count + wb.n_blocks, 0, sizeof(uint32_t), s); // blocks without a list so far
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_wf_beams, dim3(wb.n_blocks), dim3(WAVE), 0, s, sc, fr, wb);
+    return hipGetLastError();
+}
+
 hipError_t wf_generate(const DevScene&, const DevFrame& fr, const WfBuffers& wb, uint32_t first_sample, uint32_t n_samples, hipStream_t s) {
     hipError_t e = hipMemsetAsync(wb.counters, 0, WF_N_COUNTERS * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
@@ -975,11 +1282,23 @@ static void launch_trace(const DevScene& sc, const WfBuffers& wb, const uint32_t
     hipLaunchKernelGGL((k_wf_trace<COUNT, ANY>), dim3(wf_persistent_waves()), dim3(WAVE), lds, s, sc, wb, q, count_slot, cursor_slot, window_slot);
 }
 
-hipError_t wf_bounce(const DevScene& sc, const DevFrame& fr, const WfBuffers& wb, uint32_t iteration, bool counters, hipStream_t s) {
+hipError_t wf_bounce(const DevScene& sc, const DevFrame& fr, const WfBuffers& wb, uint32_t iteration, uint32_t n_samples, bool counters, hipStream_t s) {
     const dim3 sgrid(wf_shading_blocks()), sblock(256);
     uint32_t* cur_q = wb.q_ext[iteration & 1u];
     uint32_t* next_q = wb.q_ext[(iteration + 1u) & 1u];
-    if (counters) launch_trace<true, false>(sc, wb, cur_q, WF_EXT_COUNT, WF_EXT_CURSOR, WF_EXT_WINDOW, s);
+    if (iteration == 0 && wb.beam_count && n_samples && wb.n_blocks) {
+        // camera segments: every path slot of the batch holds one, sample-block sb = slots [64 sb, 64 sb + 64); from their block's leaf
+        // triangle list (k_wf_trace_camera); the blocks without a list were queued by k_wf_generate for the persistent tree walk
+        const dim3 lgrid(std::min<uint32_t>(wb.n_blocks, (uint32_t)cu_count() * 96u));
+        const size_t list_lds = (size_t)RT_BEAM_CAP * (3 * sizeof(uint4) + sizeof(float)), walk_lds = (size_t)std::max(1u, sc.stack_entries) * WAVE * sizeof(uint2);
+        if (counters) {
+            hipLaunchKernelGGL((k_wf_trace_camera<true>), lgrid, dim3(WAVE), wb.probe == 2u ? (size_t)RT_BEAM_CAP * 64 + walk_lds : list_lds, s, sc, wb, n_samples);
+            launch_trace<true, false>(sc, wb, wb.q_ext[1], WF_FB_COUNT, WF_FB_CURSOR, WF_SHADOW2_WINDOW, s);
+        } else {
+            hipLaunchKernelGGL((k_wf_trace_camera<false>), lgrid, dim3(WAVE), list_lds, s, sc, wb, n_samples);
+            launch_trace<false, false>(sc, wb, wb.q_ext[1], WF_FB_COUNT, WF_FB_CURSOR, WF_SHADOW2_WINDOW, s);
+        }
+    } else if (counters) launch_trace<true, false>(sc, wb, cur_q, WF_EXT_COUNT, WF_EXT_CURSOR, WF_EXT_WINDOW, s);
     else launch_trace<false, false>(sc, wb, cur_q, WF_EXT_COUNT, WF_EXT_CURSOR, WF_EXT_WINDOW, s);
     hipLaunchKernelGGL(k_wf_shade, sgrid, sblock, 0, s, sc, fr, wb, (const uint32_t*)cur_q);
     if ((fr.flags & 2u) == 0) {

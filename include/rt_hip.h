@@ -65,6 +65,9 @@ extern "C" {
 #define RT_FLAG_KERNEL_PIPELINE 32u /* extended mode only: always the queue pipeline, also for the frames that take the one-pass kernel */
                               /* by rule (max_bounces 0 over a tiny tree; tests and A/B measurements; same results)        */
 
+#define RT_FLAG_NO_BEAMS 64u  /* extended mode only: camera segments walk the tree like every other segment instead of testing their   */
+                              /* pixel block's leaf list (A/B measurements and tests; same results)                                 */
+
 typedef struct rt_ctx rt_ctx;
 
 typedef struct rt_render_params {

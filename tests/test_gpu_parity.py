@@ -314,6 +314,9 @@ def test_one_context_over_several_devices(gpu_ctx, oracle_mod):
     gpu_ctx.upload_scene(scene)
     one = gpu_ctx.render(w, h, scene.camera, mode=2, spp=3, max_bounces=2, frame_seed=5, tile_size=32)
     ext = gpu_ctx.read_rgb32f()
+    # long paths: past 8 bounces every device reads back how many of its paths live (round 3: polled after all devices have their
+    # launches queued, not inside the per-device loop); 9 and 17 bounces cross one and two of those polls, 40 lets every path end early
+    long_frames = {b: (gpu_ctx.render(w, h, scene.camera, mode=2, spp=2, max_bounces=b, frame_seed=6, tile_size=32), gpu_ctx.read_rgb32f().copy()) for b in (9, 17, 40)}
     for ids in ((0, 0), (0, 0, 0)):
         with type(gpu_ctx)(ids) as ctx:
             got = _render_gpu(ctx, scene, w, h, mode=1)
@@ -334,6 +337,10 @@ def test_one_context_over_several_devices(gpu_ctx, oracle_mod):
             st = ctx.render(w, h, scene.camera, mode=2, spp=3, max_bounces=2, frame_seed=5, tile_size=32)
             np.testing.assert_array_equal(ctx.read_rgb32f().view(np.uint32), ext.view(np.uint32))
             assert (st["rays"], st["shadow_rays"]) == (one["rays"], one["shadow_rays"])
+            for b, (st1, img1) in long_frames.items():
+                st = ctx.render(w, h, scene.camera, mode=2, spp=2, max_bounces=b, frame_seed=6, tile_size=32)
+                np.testing.assert_array_equal(ctx.read_rgb32f().view(np.uint32), img1.view(np.uint32))
+                assert (st["primary_rays"], st["continuation_rays"], st["shadow_rays"]) == (st1["primary_rays"], st1["continuation_rays"], st1["shadow_rays"]), b
             # a dispatch sequence on such a context is owned by its first device
             packed = oracle_mod.PackedScene(scene, use_bvh=False)
             tx, ty = H.tile_count(w, h)
