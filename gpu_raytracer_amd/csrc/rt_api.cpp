@@ -658,7 +658,10 @@ int run_frame(rt_ctx* ctx, DevFrame fr, bool counters, uint32_t world, uint32_t 
         // fixed by the CPU statement).  SURVEY 7 step 6, shader/src/lib.rs:86-88 (one write per pixel).  RT_FLAG_KERNEL_PIPELINE keeps the pipeline.
         const bool single_pass = f.mode == RT_MODE_EXTENDED && !(f.flags & (RT_FLAG_KERNEL_V1 | RT_FLAG_KERNEL_SM | RT_FLAG_KERNEL_PIPELINE)) && f.max_bounce == 0 &&
                                  ctx->scene_counts.n_nodes <= single_pass_max_nodes();
-        if (single_pass) single = true;
+        if (single_pass) {
+            single = true;
+            f.flags |= RT_FLAG_KERNEL_V1; // (launch_render_extended picks its kernel by this bit: the nested loops, not the state machine)
+        }
         const bool wavefront = f.mode == RT_MODE_EXTENDED && !(f.flags & (RT_FLAG_KERNEL_V1 | RT_FLAG_KERNEL_SM)) && !single_pass &&
                                ctx->scene_counts.n_lights <= RT_WF_MAX_LIGHTS &&
                                (uint64_t)f.n_owned_tiles * rt::blocks_per_tile(f.tile_size) * 64u <= wavefront_max_paths(ctx->scene_counts.n_lights);

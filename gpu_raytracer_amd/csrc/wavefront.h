@@ -29,7 +29,7 @@ enum WfCounter : uint32_t {
     WF_EXT_WINDOW_NEXT = 8, // ... the next extension queue
     WF_SHADOW2_CURSOR = 9,
     WF_SHADOW2_WINDOW = 10, // stays 0: the handed-on queue is written densely
-    WF_FINISH_DONE = 11,    // blocks of k_wf_finish that have ended (the last one advances the queues)
+    WF_UNUSED_11 = 11,
     WF_FB_COUNT = 12,       // camera segments of pixel blocks without a beam list (they walk the tree): entries in q_ext[1] at depth 0, dense
     WF_FB_CURSOR = 13,
     WF_N_COUNTERS = 16

@@ -10,7 +10,7 @@
 //   k_wf_trace<any hit>  persistent; shadow segments walk the BVH and set the same visibility bits
 //   k_wf_finish          sum the visible contributions IN LIGHT ORDER, add emission, then terminal shading or
 //                        continuation sampling + russian roulette; survivors go to the next extension queue
-//                        ; the last block to end moves the queue sizes on and resets the cursors (wf_advance)
+//   k_wf_advance         one thread: queue sizes move on, cursors are reset
 // Per-path arithmetic and its order are exactly those of the CPU statement (and of the megakernels in
 // kernels.hip); queues only change WHEN a path's next step runs, so images stay bit-identical.
 #include "wavefront.h"
@@ -459,6 +459,9 @@ __global__ __launch_bounds__(WAVE, RT_WF8_MIN_WAVES) void k_wf_trace(DevScene sc
 #ifndef RT_BEAM_MARGIN_PX
 #define RT_BEAM_MARGIN_PX 0.125f
 #endif
+#ifndef RT_BEAM_SAMPLES_PER_WAVE
+#define RT_BEAM_SAMPLES_PER_WAVE 8u
+#endif
 #ifndef RT_BEAM_DIST_SCALE
 #define RT_BEAM_DIST_SCALE 0.99999f
 #endif
@@ -635,8 +638,11 @@ __global__ __launch_bounds__(WAVE) void k_wf_trace_camera(DevScene sc, rt::WfBuf
     const uint32_t lane = threadIdx.x;
     float* s_d = reinterpret_cast<float*>(s_cam + RT_BEAM_CAP * 3u);
     Counts cnt = {0u, 0u};
-    for (uint32_t b = blockIdx.x; b < wb.n_blocks; b += gridDim.x) {
-        const uint32_t k_first = 0u, k_end = n_samples;
+    // one wave per (block, RT_BEAM_SAMPLES_PER_WAVE samples): a block's samples in one wave would be a chain of 22 ... 64 dependent
+    // round trips with 16 waves per CU on an eighth of the frame (2.4 ms per launch measured); staging the list again per chunk is cheap
+    const uint32_t chunks = (n_samples + RT_BEAM_SAMPLES_PER_WAVE - 1u) / RT_BEAM_SAMPLES_PER_WAVE;
+    for (uint32_t item = blockIdx.x; item < wb.n_blocks * chunks; item += gridDim.x) {
+        const uint32_t b = item / chunks, k_first = (item - b * chunks) * RT_BEAM_SAMPLES_PER_WAVE, k_end = min(n_samples, k_first + RT_BEAM_SAMPLES_PER_WAVE);
         const uint32_t n_list = (uint32_t)__builtin_amdgcn_readfirstlane((int)wb.beam_count[b]);
         if (n_list & RT_BEAM_OVERFLOW) continue; // (k_wf_generate queues this block's segments for the tree walk)
         {
@@ -1033,12 +1039,14 @@ __global__ __launch_bounds__(256, RT_WF_SHADE_WAVES) void k_wf_shade(DevScene sc
     if ((threadIdx.x & 63u) == 0 && ns) atomicAdd(&wb.totals[2], ns);
 }
 
-// End of a bounce iteration: queue sizes move on, cursors are reset.  Round 3: run by the LAST block of k_wf_finish to end instead of a
-// one-thread kernel of its own (one launch less per bounce).  Every block's appends to the next queue (atomics on
-// WF_EXT_NEXT) precede its increment of WF_FINISH_DONE, so the block that sees the full count sees the final lengths; nothing else
-// runs on these counters until the next kernel of the stream.
-__device__ __forceinline__ void wf_advance(uint32_t* c) {
-    c[rt::WF_EXT_COUNT] = atomicAdd(&c[rt::WF_EXT_NEXT], 0u);
+// End of a bounce iteration: queue sizes move on, cursors are reset (one thread, a launch of its own).  Round 3 tried it inside
+// k_wf_finish, run by the last block to end (every block: __syncthreads, __threadfence, atomicAdd on a done counter): the agent-scope
+// release fence after a kernel that has just written 64 bytes per path costs more than the launch it saves - k_wf_finish 16.9 -> 20.7 ms
+// per headline frame, +0.24 ms per launch on an eighth of it (profiles/ab_r03.json).
+__global__ void k_wf_advance(rt::WfBuffers wb) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t* c = wb.counters;
+    c[rt::WF_EXT_COUNT] = c[rt::WF_EXT_NEXT];
     c[rt::WF_EXT_WINDOW] = c[rt::WF_EXT_WINDOW_NEXT];
     c[rt::WF_EXT_NEXT] = 0;
     c[rt::WF_SHADOW_COUNT] = 0;
@@ -1046,7 +1054,6 @@ __device__ __forceinline__ void wf_advance(uint32_t* c) {
     c[rt::WF_SHADOW2_CURSOR] = 0;
     c[rt::WF_EXT_CURSOR] = 0;
     c[rt::WF_SHADOW_CURSOR] = 0;
-    c[rt::WF_FINISH_DONE] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1187,11 +1194,6 @@ __global__ __launch_bounds__(256, RT_WF_SHADE_WAVES) void k_wf_finish(DevScene s
     window_close(next_queue, win);
     const unsigned long long nc = wave_sum(n_cont);
     if ((threadIdx.x & 63u) == 0 && nc) atomicAdd(&wb.totals[1], nc);
-    __syncthreads(); // (every wave of the block has made its last reservation)
-    if (threadIdx.x == 0) {
-        __threadfence();
-        if (atomicAdd(&wb.counters[rt::WF_FINISH_DONE], 1u) == gridDim.x - 1u) wf_advance(wb.counters);
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1289,7 +1291,7 @@ hipError_t wf_bounce(const DevScene& sc, const DevFrame& fr, const WfBuffers& wb
     if (iteration == 0 && wb.beam_count && n_samples && wb.n_blocks) {
         // camera segments: every path slot of the batch holds one, sample-block sb = slots [64 sb, 64 sb + 64); from their block's leaf
         // triangle list (k_wf_trace_camera); the blocks without a list were queued by k_wf_generate for the persistent tree walk
-        const dim3 lgrid(std::min<uint32_t>(wb.n_blocks, (uint32_t)cu_count() * 96u));
+        const dim3 lgrid(std::min<uint32_t>(wb.n_blocks * ((n_samples + RT_BEAM_SAMPLES_PER_WAVE - 1u) / RT_BEAM_SAMPLES_PER_WAVE), (uint32_t)cu_count() * 96u));
         const size_t list_lds = (size_t)RT_BEAM_CAP * (3 * sizeof(uint4) + sizeof(float)), walk_lds = (size_t)std::max(1u, sc.stack_entries) * WAVE * sizeof(uint2);
         if (counters) {
             hipLaunchKernelGGL((k_wf_trace_camera<true>), lgrid, dim3(WAVE), wb.probe == 2u ? (size_t)RT_BEAM_CAP * 64 + walk_lds : list_lds, s, sc, wb, n_samples);
@@ -1311,7 +1313,8 @@ hipError_t wf_bounce(const DevScene& sc, const DevFrame& fr, const WfBuffers& wb
         } else if (counters) launch_trace<true, true>(sc, wb, wb.q_shadow, WF_SHADOW_COUNT, WF_SHADOW_CURSOR, WF_SHADOW_WINDOW, s);
         else launch_trace<false, true>(sc, wb, wb.q_shadow, WF_SHADOW_COUNT, WF_SHADOW_CURSOR, WF_SHADOW_WINDOW, s);
     }
-    hipLaunchKernelGGL(k_wf_finish, sgrid, sblock, 0, s, sc, fr, wb, (const uint32_t*)cur_q, next_q); // (its last block advances the queues)
+    hipLaunchKernelGGL(k_wf_finish, sgrid, sblock, 0, s, sc, fr, wb, (const uint32_t*)cur_q, next_q);
+    hipLaunchKernelGGL(k_wf_advance, dim3(1), dim3(1), 0, s, wb);
     return hipGetLastError();
 }
 

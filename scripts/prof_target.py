@@ -5,7 +5,7 @@ from gpu_raytracer_amd import api, scenes
 spp, bounces, reps = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 v1 = len(sys.argv) > 4 and sys.argv[4] == "v1"
 sm = len(sys.argv) > 4 and sys.argv[4] == "sm"
-sp = scenes.sponza_like()
+sp = scenes.SCENES[os.environ.get("RT_PROF_SCENE", "sponza_like")]()
 with api.Context() as ctx:
     ctx.upload_scene(sp)
     for _ in range(reps):
