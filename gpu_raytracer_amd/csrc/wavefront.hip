@@ -29,6 +29,9 @@ using namespace rtdev;
 #define RT_WF_CHUNK 256 /* queue entries a wave claims per atomic (64 / 128: -37 % / -6 %, cursor atomics; 1024 / 2048 / 8192: -1.5 / -5 / -12 %: small chunks keep the
                            waves on neighbouring parts of the queue, i.e. on neighbouring rays) */
 #endif
+#ifndef RT_WF_ADAPTIVE_CHUNK
+#define RT_WF_ADAPTIVE_CHUNK 1
+#endif
 #ifndef RT_WF_WINDOW
 #define RT_WF_WINDOW 512 /* queue slots a producing wave reserves per atomic */
 #endif
@@ -223,6 +226,16 @@ __global__ __launch_bounds__(WAVE, RT_WF8_MIN_WAVES) void k_wf_trace(DevScene sc
     const uint32_t count = wb.counters[count_slot];
     const uint32_t window_mask = max(wb.counters[window_slot], 1u) - 1u;
     uint32_t* cursor = &wb.counters[cursor_slot];
+    // Queue entries a wave claims per atomic: RT_WF_CHUNK (256) when the queue holds that much for every wave; a short queue - the shadow
+    // segments the light grids hand on (2 % of them: 0.5 M entries per launch), the camera segments without a beam list, the last
+    // bounces - is shared out in smaller chunks, down to one wave-load: the launch then ends after one generation of segments per wave
+    // instead of four (the drain was ~0.2 ms of every such launch; 60 of them in a headline frame)
+#if RT_WF_ADAPTIVE_CHUNK
+    uint32_t chunk = RT_WF_CHUNK;
+    while (chunk > WAVE && (unsigned long long)chunk * gridDim.x > count) chunk >>= 1;
+#else
+    const uint32_t chunk = RT_WF_CHUNK;
+#endif
     Counts cnt = {0u, 0u};
     int sp_max = 0;
     uint32_t d_node_steps = 0, d_leaf_steps = 0, d_leaf_lanes = 0, d_leaf_trips = 0, d_refills = 0;
@@ -251,10 +264,10 @@ __global__ __launch_bounds__(WAVE, RT_WF8_MIN_WAVES) void k_wf_trace(DevScene sc
         if (!exhausted && (__popcll(idle) >= RT_WF_REFILL || idle == ~0ull)) {
             if (chunk_next >= chunk_end) {
                 uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(cursor, (uint32_t)RT_WF_CHUNK);
+                if (lane == 0) base = atomicAdd(cursor, chunk);
                 base = __shfl(base, 0, WAVE);
                 chunk_next = base;
-                chunk_end = min(base + (uint32_t)RT_WF_CHUNK, count);
+                chunk_end = min(base + chunk, count);
                 if (base >= count) exhausted = true;
             }
             if (!exhausted) {
@@ -772,8 +785,12 @@ static_assert(RT_WF_GRID_WALK < RT_SG_SORTED_PREFIX, "a walk may only look at th
 #ifndef RT_WF_GRID_BLOCKS_PER_CU
 #define RT_WF_GRID_BLOCKS_PER_CU 16 /* 256-thread blocks per CU: 8 measured 3 % slower, 4 the same as 8 */
 #endif
+#ifndef RT_WF_GRID_MIN_WAVES
+#define RT_WF_GRID_MIN_WAVES 7 /* waves per SIMD the list walk is register-allocated for: 8 (64 VGPRs) spills five registers inside its loop - scratch
+                                traffic in a stage bound by memory requests; 7 (72 VGPRs): -2.7 % on the headline frame, 6 the same (profiles/ab_r03.json) */
+#endif
 template <bool COUNT>
-__global__ __launch_bounds__(256, 8) void k_wf_shadow_grid(DevScene sc, rt::WfBuffers wb) {
+__global__ __launch_bounds__(256, RT_WF_GRID_MIN_WAVES) void k_wf_shadow_grid(DevScene sc, rt::WfBuffers wb) {
     __shared__ DevLight s_lights[RT_WF_MAX_LIGHTS];
     __shared__ DevShadowGrid s_grids[RT_WF_MAX_LIGHTS];
     __shared__ uint32_t s_fwd[4][128]; // per wave: entries to hand on, not yet appended
