@@ -301,9 +301,9 @@ def main():
 
     part_world = args.share_of if (args.share_of > 1 and n_gpus == 1) else n_gpus
 
-    def step(counters=False):
+    def step(counters=False, stage_times=False):
         return ctx.render(args.width, args.height, scene.camera, mode=mode, spp=spp, max_bounces=bounces,
-                          tile_size=tile, tile_rank=rank, tile_world=part_world, counters=counters,
+                          tile_size=tile, tile_rank=rank, tile_world=part_world, counters=counters, stage_times=stage_times,
                           kernel_sm=args.kernel == "state_machine", kernel_v1=args.kernel == "nested")
 
     for _ in range(args.warmup):
@@ -334,12 +334,17 @@ def main():
 
     # exact node / triangle fetch counts and wave-level step statistics from the counting variant of the same kernels
     # the same frame on one lane (RT_WF_LANES=1: every stage kernel alone on the chip) - what the rocprofv3 summaries under profiles/ time
-    one_lane_ms = None
+    one_lane_ms, grid_ms, grid_launches = None, 0.0, 0
     if mode_name == "extended" and os.environ.get("RT_WF_LANES") is None:
         os.environ["RT_WF_LANES"] = "1"
         try:
             step()
-            one_lane_ms = float(np.mean([step()["kernel_ms"] for _ in range(2)]))
+            one_lane, grid_ms, grid_launches = [], 0.0, 0
+            for _ in range(2):
+                one_lane.append(step(stage_times=args.kernel == "wavefront")["kernel_ms"])
+                ms, n = ctx.debug_stage_times()  # every k_wf_shadow_grid launch of the frame, HIP events on the stream it was launched on
+                grid_ms, grid_launches = grid_ms + ms, grid_launches + n
+            one_lane_ms = float(np.mean(one_lane))
         finally:
             del os.environ["RT_WF_LANES"]
         step()
@@ -369,34 +374,58 @@ def main():
         workload = f"{scene.name} {scene.n_triangles} tris {args.width}x{args.height} {spp} spp " + \
                    (f"{bounces} bounces (extended mode)" if mode_name == "extended" else
                     "primary rays, reference semantics (mode 1: one pixel-centre ray per pixel; the reference has no spp/bounces)")
-        achieved_bytes, achieved_src = (traffic, f"rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/traffic.json@{prof['source_sha16']}") if traffic is not None else \
-            (compulsory_bytes, "no counter profile for this build of the kernels: path-state + pixel + scene bytes that must cross HBM (lower bound)")
-        achieved = achieved_bytes / (avg_kernel_ms * 1e-3) / 1e9
-        roofline = {
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "achieved_source": achieved_src,
-            "traffic": traffic, "traffic_source": f"profiles/traffic.json@{prof['source_sha16']} ({prof.get('profile', '')})" if prof else None,
-            "hbm_counter_frac": (traffic / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic is not None else None,
-            "kernel": "k_render_reference" if mode_name == "reference" else
-                      "wavefront pipeline, all stage kernels of one frame (k_wf_shadow_grid + k_wf_trace<shadow> + k_wf_trace<closest> + k_wf_shade + k_wf_finish + k_wf_generate + k_wf_resolve)",
-            "kernel_avg_ms": avg_kernel_ms,
-            "kernel_avg_ms_one_lane": one_lane_ms,
-            "compulsory_hbm_bytes_per_launch": compulsory_bytes,
-            "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_GBps": alg_bytes / (avg_kernel_ms * 1e-3) / 1e9,
+        frame = {  # the whole pipeline, one frame (all stage kernels, HIP events on the launch stream)
+            "kernel_avg_ms": avg_kernel_ms, "kernel_avg_ms_one_lane": one_lane_ms,
+            "traffic": traffic, "traffic_source": f"profiles/traffic.json@{prof['source_sha16']} ({prof.get('profile', '')}): per-kernel FETCH_SIZE x read factor + WRITE_SIZE" if prof else None,
+            "hbm_GBps": (traffic / (avg_kernel_ms * 1e-3) / 1e9) if traffic is not None else None,
+            "hbm_frac": (traffic / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic is not None else None,
+            "compulsory_hbm_bytes": compulsory_bytes,
+            "algorithmic_bytes": alg_bytes, "algorithmic_GBps": alg_bytes / (avg_kernel_ms * 1e-3) / 1e9,
             "state_bytes_per_segment": {"extension": S_STATE_EXTENSION, "shadow": S_STATE_SHADOW, "path": S_STATE_PATH} if wavefront else None,
             "nodes_per_ray": stc["node_visits"] / max(stc["rays"], 1), "tris_per_ray": stc["tri_tests"] / max(stc["rays"], 1),
-            "practical_bound": "VALU issue of the traversal kernels (branchy scalar f32, no MFMA; the tree is cache resident) and the rate of "
-                               "scattered line fetches of the light-grid stage (44-55 G lines/s measured, scripts/micro/random_read.hip); see `issue`",
-            "shadow_grids": {"lights_with_grid": grid["lights_with_grid"], "bytes": grid["bytes"], "entries": grid["entries"],
-                             "shadow_segments_answered_share": grid["segments_answered"] / max(stc["shadow_rays"], 1),
-                             "entries_read_per_answered_segment": grid["entries_read"] / max(grid["segments_answered"], 1)} if wavefront else None,
-            "note": "launch = one frame on rank 0 (all stage kernels, HIP events on the launch stream; with light grids the batches run on two "
-                    "streams and their kernels overlap: kernel_avg_ms_one_lane is the same frame with RT_WF_LANES=1, which is what the per-kernel "
-                    "rocprofv3 summaries under profiles/ add up to).  achieved/frac: HBM-side bytes "
-                    "from the committed PMC passes of this very build (FETCH_SIZE is uncalibrated for 16-byte gathers, "
-                    "MI355X_MICROARCH.md).  algorithmic_*: SURVEY 8d's per-segment figure (node fetches x 80 B + triangle fetches x "
-                    "48 B + per-kind path state + pixels x 36 B); ~90 % of it is served by L1/L2, so it is a rate, not an HBM fraction",
+            "note": "algorithmic_*: SURVEY 8d's per-segment figure over every kernel (node fetches x 80 B + triangle fetches x 48 B + per-kind path state + "
+                    "pixels x 36 B); ~90 % of it is served by L1/L2 (the scene is 28 MB), so it is a rate, not an HBM fraction",
         }
+        dom = prof.get("dominant_kernel") if prof else None
+        if wavefront and grid_launches and grid["lights_with_grid"]:
+            # SURVEY 8d / DESIGN 4 for the dominant kernel k_wf_shadow_grid, per launch: every shadow segment reads its queue entry and vertex and
+            # sets one visibility bit (44 B), every answered one reads its cell's header (8 B) and 48 B per list entry it looks at
+            launches_per_frame = grid_launches / 2.0
+            alg_grid = (grid["entries_read"] * 48 + grid["segments_answered"] * 8 + stc["shadow_rays"] * S_STATE_SHADOW) / launches_per_frame
+            launch_ms = grid_ms / grid_launches
+            achieved = alg_grid / (launch_ms * 1e-3) / 1e9
+            dom_traffic = dom.get("hbm_bytes_per_launch") if dom and dom.get("name") == "k_wf_shadow_grid" else None
+            roofline = {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": dom_traffic,
+                "kernel": "k_wf_shadow_grid", "launches_per_frame": launches_per_frame, "avg_launch_ms": launch_ms,
+                "algorithmic_bytes_per_launch": alg_grid, "share_of_one_lane_frame": grid_ms / 2.0 / one_lane_ms if one_lane_ms else None,
+                "traffic_over_algorithmic": (dom_traffic / alg_grid) if dom_traffic else None,
+                "achieved_source": "algorithmic bytes per launch (counting variant of the same kernels, this run) / average duration of the kernel's launches, HIP events on "
+                                   "their stream, frames on one lane (this run); traffic: FETCH_SIZE x 1 + WRITE_SIZE of the committed PMC passes of this build - its reads are "
+                                   "scattered 16-byte quads, for which FETCH_SIZE counts requests of 64 bytes (profiles/r03_fetch_calibration.json)",
+                "practical_bound": "the rate of scattered memory requests: every segment is a chain queue entry -> vertex -> cell block -> (further entries), ~1.8 L2 misses; "
+                                   "fewer requests per segment (packed cell blocks) and more requests in flight (prefetching the chain's head) both measured no faster "
+                                   "(profiles/ab_r03.json)",
+                "read_requests_per_s": dom.get("read_requests_per_s") if dom else None,
+                "shadow_grids": {"lights_with_grid": grid["lights_with_grid"], "bytes": grid["bytes"], "entries": grid["entries"],
+                                 "shadow_segments_answered_share": grid["segments_answered"] / max(stc["shadow_rays"], 1),
+                                 "entries_read_per_answered_segment": grid["entries_read"] / max(grid["segments_answered"], 1)},
+                "second_kernel": {"name": "k_wf_trace<closest> (+ k_wf_trace_camera)", "bound": "VALU issue (branchy scalar f32, no MFMA; the tree is cache resident): see `issue`"},
+                "frame": frame,
+            }
+        else:  # reference mode, or the megakernels: the frame is one kernel
+            achieved_bytes = traffic if traffic is not None else compulsory_bytes
+            achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
+            roofline = {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel": "k_render_reference" if mode_name == "reference" else args.kernel, "avg_launch_ms": avg_kernel_ms,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "achieved_source": "algorithmic bytes (node fetches x 80 B + triangle fetches x 48 B + pixels x 36 B, counting variant of the same kernel) / kernel time (HIP events); "
+                                   "the scene is cache resident, so this rate is served by L1 / L2, not by HBM: see hbm_bytes",
+                "hbm_bytes": achieved_bytes, "hbm_frac": achieved_bytes / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "practical_bound": "VALU issue and memory latency of the per-lane tree walk (branchy scalar f32, no MFMA)",
+                "frame": frame,
+            }
         if wavefront and diag[3] > 0:
             roofline["issue"] = {
                 "node_step_lane_utilisation": stc["node_visits"] / (diag[3] * 64.0),
@@ -408,8 +437,8 @@ def main():
                 "source": "RT_FLAG_COUNTERS variant of the same kernels (this run); valu_busy = 4 x SQ_ACTIVE_INST_VALU / (kernel time x "
                           "2.4 GHz x 1024 SIMDs) from the committed SQ pass",
             }
-        if prof and prof.get("dominant_kernel"):
-            roofline["dominant_kernel"] = prof["dominant_kernel"]
+        if dom:
+            roofline["profile_dominant_kernel"] = dom
         out = {
             "metric": "Mrays/s", "value": metric_rays / dt / 1e6, "unit": "Mrays/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,

@@ -24,6 +24,7 @@ FLAG_KERNEL_SM = 8
 FLAG_NO_SHADOW_GRID = 16
 FLAG_KERNEL_PIPELINE = 32
 FLAG_NO_BEAMS = 64
+FLAG_STAGE_TIMES = 128
 PREPARE_SHADOW_GRIDS = 1
 EXTENDED_AVAILABLE = True
 
@@ -138,12 +139,12 @@ class Context:
 
     # -- rendering -------------------------------------------------------------------
     def render(self, width, height, camera, mode=MODE_LEGACY, spp=1, max_bounces=4, frame_seed=0, tile_size=0,
-               tile_rank=0, tile_world=1, counters=False, no_shadows=False, kernel_v1=False, kernel_sm=False, no_shadow_grid=False, kernel_pipeline=False, no_beams=False):
+               tile_rank=0, tile_world=1, counters=False, no_shadows=False, kernel_v1=False, kernel_sm=False, no_shadow_grid=False, kernel_pipeline=False, no_beams=False, stage_times=False):
         p = np.zeros((), dtype=T.RENDER_PARAMS)
         p["camera"] = camera
         p["width"], p["height"], p["spp"], p["max_bounces"], p["mode"] = width, height, spp, max_bounces, mode
         p["frame_seed"], p["tile_size"], p["tile_rank"], p["tile_world"] = frame_seed, tile_size, tile_rank, tile_world
-        p["flags"] = (FLAG_COUNTERS if counters else 0) | (FLAG_NO_SHADOWS if no_shadows else 0) | (FLAG_KERNEL_V1 if kernel_v1 else 0) | (FLAG_KERNEL_SM if kernel_sm else 0) | (FLAG_NO_SHADOW_GRID if no_shadow_grid else 0) | (FLAG_KERNEL_PIPELINE if kernel_pipeline else 0) | (FLAG_NO_BEAMS if no_beams else 0)
+        p["flags"] = (FLAG_COUNTERS if counters else 0) | (FLAG_NO_SHADOWS if no_shadows else 0) | (FLAG_KERNEL_V1 if kernel_v1 else 0) | (FLAG_KERNEL_SM if kernel_sm else 0) | (FLAG_NO_SHADOW_GRID if no_shadow_grid else 0) | (FLAG_KERNEL_PIPELINE if kernel_pipeline else 0) | (FLAG_NO_BEAMS if no_beams else 0) | (FLAG_STAGE_TIMES if stage_times else 0)
         self._check(self.lib.rt_render(self._h, _p(p)))
         self.width, self.height = width, height
         return self.stats()
@@ -183,6 +184,12 @@ class Context:
         if m < 0:
             raise RtError(m, "rt_debug_beams")
         return out[:m]
+
+    def debug_stage_times(self):
+        """(sum of the k_wf_shadow_grid launch durations in ms, launches) of the last frame rendered with stage_times=True."""
+        out = (C.c_double * 2)()
+        self._check(self.lib.rt_debug_stage_times(self._h, out))
+        return float(out[0]), int(out[1])
 
     def debug_counters(self):
         out = (C.c_ulonglong * 8)()

@@ -66,6 +66,8 @@ struct DeviceState {
     bool used_two_lanes = false;
     uint32_t wf_lights = 0;
     uint32_t wf_spp = 0; // spp the current wavefront allocation was sized for
+    std::vector<hipEvent_t> stage_events; // RT_FLAG_STAGE_TIMES: event pairs around the launches of the dominant stage kernel
+    uint32_t stage_events_used = 0;
     bool wf_beams_off = false; // this frame walks the tree for its camera segments too (RT_FLAG_NO_BEAMS)
     std::vector<void*> wf_allocs;
 };
@@ -83,6 +85,7 @@ struct rt_ctx {
     bool frame_valid = false;
     unsigned long long diag[8] = {0}; // diagnostics of the counting kernel variant (rt_debug_counters)
     unsigned long long grid_diag[2] = {0}; // ... of the light grids: shadow segments they answered, list entries read
+    double stage_ms[2] = {0.0, 0.0};       // RT_FLAG_STAGE_TIMES: [0] sum of the k_wf_shadow_grid launch durations of the last frame (device 0), [1] launches
     int fail_upload_at = -1;          // test hook: the next scene upload fails before its k-th device array (rt_debug_fail_upload)
     uint32_t n_input_tris = 0;        // triangles handed to the last scene upload (prim ids are < this)
     int build_method = 0;             // how its tree was built: 0 host SAH, 1 host PLOC, 2 device PLOC
@@ -583,7 +586,14 @@ uint32_t wavefront_batch(uint32_t n_blocks, uint32_t spp, uint32_t n_lights, siz
     target_paths = std::min<uint64_t>(target_paths, wavefront_max_paths(n_lights));
     uint32_t max_batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(spp, target_paths / per_sample));
     if (two_lanes && spp >= 2) max_batch = std::min(max_batch, (spp + 1) / 2); // two lanes want two batches, also of a frame that would fit one
-    const uint32_t n_batches = (spp + max_batch - 1) / max_batch;
+    uint32_t n_batches = (spp + max_batch - 1) / max_batch;
+    if (two_lanes && n_batches > 1 && (n_batches & 1u)) {
+        // an even number of batches, so that both lanes get the same share (measured on the headline frame, round 3: 3 batches of 22/21/21
+        // samples 176.8 ms, 2 of 32 170.9, 4 of 16 174.3): one batch fewer if that stays within a tenth of the target and the hard limits
+        const uint32_t fewer = n_batches - 1, b = (spp + fewer - 1) / fewer;
+        if ((uint64_t)b * per_sample * 10 <= target_paths * 11 && b <= hard_limit && (uint64_t)b * per_sample <= free_bytes / 2 / bytes_per_path) n_batches = fewer;
+        else n_batches++;
+    }
     return std::max(1u, (spp + n_batches - 1) / std::max(1u, n_batches));
 }
 
@@ -631,6 +641,8 @@ int run_frame(rt_ctx* ctx, DevFrame fr, bool counters, uint32_t world, uint32_t 
     };
     std::vector<WfRun> runs;
     runs.reserve(nd); // (polls hold pointers into it)
+    for (size_t j = 0; j < nd; j++) ctx->devs[j].stage_events_used = 0;
+    ctx->stage_ms[0] = ctx->stage_ms[1] = 0.0;
     for (size_t j = 0; j < nd; j++) {
         DeviceState& d = ctx->devs[j];
         HIPCHK(ctx, hipSetDevice(d.device));
@@ -742,7 +754,19 @@ int run_frame(rt_ctx* ctx, DevFrame fr, bool counters, uint32_t world, uint32_t 
                 r.it = 0;
                 r.phase = WfRun::BOUNCE;
             } else if (r.phase == WfRun::BOUNCE) {
-                HIPCHK(ctx, rt::wf_bounce(r.dsc, r.f, w, r.it, n, counters, st));
+                hipEvent_t* gev = nullptr;
+                if ((r.f.flags & RT_FLAG_STAGE_TIMES) && r.dev == 0 && w.grids) { // (bench.py: the dominant kernel's launch durations, measured live)
+                    if (d.stage_events.size() < (size_t)d.stage_events_used + 2) {
+                        hipEvent_t a = nullptr, b = nullptr;
+                        HIPCHK(ctx, hipEventCreate(&a));
+                        HIPCHK(ctx, hipEventCreate(&b));
+                        d.stage_events.push_back(a);
+                        d.stage_events.push_back(b);
+                    }
+                    gev = d.stage_events.data() + d.stage_events_used;
+                    d.stage_events_used += 2;
+                }
+                HIPCHK(ctx, rt::wf_bounce(r.dsc, r.f, w, r.it, n, counters, st, gev));
                 if (r.it >= r.f.max_bounce) r.phase = WfRun::RESOLVE;
                 else if ((r.it & 7u) == 7u) {
                     HIPCHK(ctx, hipMemcpyAsync(&r.alive, w.counters + rt::WF_EXT_COUNT, 4, hipMemcpyDeviceToHost, st));
@@ -796,6 +820,15 @@ int run_frame(rt_ctx* ctx, DevFrame fr, bool counters, uint32_t world, uint32_t 
         float ms = 0.0f;
         HIPCHK(ctx, hipEventElapsedTime(&ms, d.ev0, d.ev1));
         kernel_ms = std::max(kernel_ms, (double)ms);
+        if (j == 0 && d.stage_events_used) {
+            if (d.stream2) HIPCHK(ctx, hipStreamSynchronize(d.stream2));
+            for (uint32_t k = 0; k + 1 < d.stage_events_used; k += 2) {
+                float sm = 0.0f;
+                HIPCHK(ctx, hipEventElapsedTime(&sm, d.stage_events[k], d.stage_events[k + 1]));
+                ctx->stage_ms[0] += sm;
+                ctx->stage_ms[1] += 1.0;
+            }
+        }
         if (extended && d.used_wavefront) {
             unsigned long long t[16];
             HIPCHK(ctx, hipMemcpy(t, d.wf.totals, sizeof t, hipMemcpyDeviceToHost));
@@ -956,6 +989,7 @@ void rt_destroy(rt_ctx* ctx) {
         if (d.ev1) (void)hipEventDestroy(d.ev1);
         for (hipEvent_t e : {d.ev_start, d.ev_join, d.ev_res[0], d.ev_res[1]})
             if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : d.stage_events) (void)hipEventDestroy(e);
         if (d.stream2) (void)hipStreamDestroy(d.stream2);
         if (d.stream) (void)hipStreamDestroy(d.stream);
     }
@@ -1338,6 +1372,15 @@ int rt_debug_beams(rt_ctx* ctx, uint32_t* counts, uint32_t n) {
     for (uint32_t i = 0; i < m; i++)
         if (counts[i] & RT_BEAM_OVERFLOW) counts[i] = 0xFFFFFFFFu;
     return (int)m;
+}
+
+// Development aid / bench.py: with RT_FLAG_STAGE_TIMES, the launches of the frame's dominant stage kernel (k_wf_shadow_grid) on the first
+// device, timed with HIP events on the stream they were launched on: out[0] sum of their durations in ms, out[1] their number.
+int rt_debug_stage_times(rt_ctx* ctx, double out[2]) {
+    if (!ctx || !out) return RT_ERR_BAD_ARG;
+    out[0] = ctx->stage_ms[0];
+    out[1] = ctx->stage_ms[1];
+    return RT_OK;
 }
 
 int rt_debug_counters(rt_ctx* ctx, unsigned long long out[8]) {

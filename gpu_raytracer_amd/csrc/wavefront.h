@@ -86,7 +86,8 @@ uint32_t wf_pick_window(uint32_t iterations, uint32_t per_lane); // the reservat
 uint32_t wf_persistent_waves(); // grid size (in 64-lane blocks) of the persistent traversal kernels on the current device
 hipError_t wf_beams(const DevScene& sc, const DevFrame& fr, const WfBuffers& wb, hipStream_t s); // once per frame and device, before the batches
 hipError_t wf_generate(const DevScene& sc, const DevFrame& fr, const WfBuffers& wb, uint32_t first_sample, uint32_t n_samples, hipStream_t s);
-hipError_t wf_bounce(const DevScene& sc, const DevFrame& fr, const WfBuffers& wb, uint32_t iteration, uint32_t n_samples, bool counters, hipStream_t s); // n_samples: samples per pixel in this batch (iteration 0)
+hipError_t wf_bounce(const DevScene& sc, const DevFrame& fr, const WfBuffers& wb, uint32_t iteration, uint32_t n_samples, bool counters, hipStream_t s,
+                     hipEvent_t* grid_events = nullptr); // n_samples: samples per pixel in this batch (iteration 0); grid_events: two events recorded around the k_wf_shadow_grid launch
 hipError_t wf_resolve(const DevFrame& fr, const WfBuffers& wb, const DevTargets& tg, uint32_t n_samples, bool first_batch, bool last_batch, hipStream_t s);
 
 } // namespace rt

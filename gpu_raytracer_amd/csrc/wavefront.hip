@@ -1301,7 +1301,7 @@ static void launch_trace(const DevScene& sc, const WfBuffers& wb, const uint32_t
     hipLaunchKernelGGL((k_wf_trace<COUNT, ANY>), dim3(wf_persistent_waves()), dim3(WAVE), lds, s, sc, wb, q, count_slot, cursor_slot, window_slot);
 }
 
-hipError_t wf_bounce(const DevScene& sc, const DevFrame& fr, const WfBuffers& wb, uint32_t iteration, uint32_t n_samples, bool counters, hipStream_t s) {
+hipError_t wf_bounce(const DevScene& sc, const DevFrame& fr, const WfBuffers& wb, uint32_t iteration, uint32_t n_samples, bool counters, hipStream_t s, hipEvent_t* grid_events) {
     const dim3 sgrid(wf_shading_blocks()), sblock(256);
     uint32_t* cur_q = wb.q_ext[iteration & 1u];
     uint32_t* next_q = wb.q_ext[(iteration + 1u) & 1u];
@@ -1323,8 +1323,10 @@ hipError_t wf_bounce(const DevScene& sc, const DevFrame& fr, const WfBuffers& wb
     if ((fr.flags & 2u) == 0) {
         if (wb.grids) { // the light grids answer what they can and hand the rest on to the traversal
             const dim3 ggrid((uint32_t)(cu_count() * RT_WF_GRID_BLOCKS_PER_CU));
+            if (grid_events) (void)hipEventRecord(grid_events[0], s);
             if (counters) hipLaunchKernelGGL(k_wf_shadow_grid<true>, ggrid, dim3(256), 0, s, sc, wb);
             else hipLaunchKernelGGL(k_wf_shadow_grid<false>, ggrid, dim3(256), 0, s, sc, wb);
+            if (grid_events) (void)hipEventRecord(grid_events[1], s);
             if (counters) launch_trace<true, true>(sc, wb, wb.q_shadow2, WF_SHADOW2_COUNT, WF_SHADOW2_CURSOR, WF_SHADOW2_WINDOW, s);
             else launch_trace<false, true>(sc, wb, wb.q_shadow2, WF_SHADOW2_COUNT, WF_SHADOW2_CURSOR, WF_SHADOW2_WINDOW, s);
         } else if (counters) launch_trace<true, true>(sc, wb, wb.q_shadow, WF_SHADOW_COUNT, WF_SHADOW_CURSOR, WF_SHADOW_WINDOW, s);

@@ -68,6 +68,9 @@ extern "C" {
 #define RT_FLAG_NO_BEAMS 64u  /* extended mode only: camera segments walk the tree like every other segment instead of testing their   */
                               /* pixel block's leaf list (A/B measurements and tests; same results)                                 */
 
+#define RT_FLAG_STAGE_TIMES 128u /* extended mode only: time every launch of the frame's dominant stage kernel with HIP events on its stream  */
+                              /* (bench.py's roofline of that kernel; read with rt_debug_stage_times)                                   */
+
 typedef struct rt_ctx rt_ctx;
 
 typedef struct rt_render_params {
