@@ -102,7 +102,14 @@ def test_extended_full_size_properties(gpu_ctx):
 @pytest.mark.parametrize("n_lights", [9, 32, 40])
 def test_extended_many_lights(gpu_ctx, oracle_mod, n_lights):
     """Shadow-queue windows grow with the light count (>= 128 slots per light), visibility is one bit per light in a
-    32-bit word, and more than 32 lights take the state-machine megakernel: all bit-exact against the CPU statement."""
+    32-bit word, and more than 32 lights take the state-machine megakernel: all bit-exact against the CPU statement.
+
+    Record: this test was red once, in gpurun_out/r02_pytest7.log (round 2, 17:32), at exactly 32 lights, 13 % of
+    the pixels.  The tree then held an uncommitted experiment - k_wf_shade handing k_wf_finish the mask of contributing lights PACKED
+    BESIDE the visibility bits in the same 32-bit word of the vertex record (profiles/ab_r02.json, "k_wf_shade hands k_wf_finish the
+    mask of contributing lights", kept: false).  The word has room for both only below 32 lights; at RT_WF_MAX_LIGHTS the two fields
+    overlapped and lights were dropped or lit wrongly.  The experiment measured no gain and was removed in 9a2666d seven minutes later,
+    before anything of it was committed; the visibility word has been visibility only ever since (`1u << li`, li < 32)."""
     scene = scenes.random_soup(600, seed=5, size=0.6, n_spheres=1, n_lights=n_lights)
     ref = oracle_mod.render_extended(oracle_mod.PackedScene(scene, use_bvh=False), 64, 40, 3, 2, frame_seed=3)
     rgb, st = _gpu_ext(gpu_ctx, scene, 64, 40, 3, 2, frame_seed=3)
