@@ -39,7 +39,6 @@ with api.Context() as ctx:
         sc = scenes.Scene(sc.name, sc.spheres, np.array(lights, dtype=T.LIGHT), sc.vertices, sc.triangles, sc.materials, sc.camera)
         ctx.upload_scene(sc)
         ctx.prepare()
-    ctx.prepare()
         g = ctx.debug_shadow_grid()
         with_grid += g["lights_with_grid"]
         for _ in range(3):
