@@ -70,7 +70,9 @@ struct WfBuffers {
     uint32_t probe;      // development probes of the counting kernel variants (RT_WF_PROBE), 0 otherwise
 };
 
-#define RT_BEAM_CAP 128u /* triangles per block list; 98 % of the headline frame's blocks need fewer */
+#ifndef RT_BEAM_CAP
+#define RT_BEAM_CAP 128u /* triangles per block list: 90 % of the headline frame's blocks need fewer (64 / 192 / 256 measured in profiles/ab_r03.json) */
+#endif
 #define RT_BEAM_OVERFLOW 0x80000000u /* beam_count[b]: this bit = no list; the low bits then number the blocks without a list (their place in the walk queue) */
 #define WF_TOTAL_ERROR 15 /* totals[] slot: non-zero = a queue reservation did not fit; every later stage kernel of the frame returns at once */
 #ifndef RT_WF8_LDS_STACK

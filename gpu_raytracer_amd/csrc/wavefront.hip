@@ -51,7 +51,7 @@ using namespace rtdev;
 namespace {
 
 __device__ __forceinline__ V3 f4v(float4 a) { return v3(a.x, a.y, a.z); }
-#define RT_KEEP4_EARLY(v) asm volatile("" : "+v"((v).x), "+v"((v).y), "+v"((v).z), "+v"((v).w))
+#define RT_KEEP4_EARLY(v) asm volatile("" : "+v"((v).x), "+v"((v).y), "+v"((v).z), "+v"((v).w)) /* (RT_KEEP4, usable before its definition below) */
 
 // Queue output through wave-private windows.  A single counter sustains ~90 M atomics/s (MI355X_MICROARCH.md,
 // "dequeue"): one atomic per wave-iteration made the shading stages atomic-bound, and so did fixed 512-slot
@@ -640,10 +640,10 @@ __global__ __launch_bounds__(WAVE) void k_wf_beams(DevScene sc, DevFrame fr, rt:
     if (lane == 0) wb.beam_count[b] = n_tri;
 }
 
-// Depth-0 closest hits from the block lists.  One wave per pixel block: the list's triangle records are staged in LDS once and every
-// sample of the block's 64 pixels (path slots (b * n_samples + k) * 64 + lane, as k_wf_generate lays them out) is tested against them,
-// all lanes on the same triangle (broadcast LDS reads).  Blocks without a list are skipped: k_wf_generate put their segments on a
-// queue of their own for k_wf_trace.
+// Depth-0 closest hits from the block lists.  One wave per (pixel block, RT_BEAM_SAMPLES_PER_WAVE samples): the list's triangle records are
+// staged in LDS and those samples of the block's 64 pixels (path slots (b * n_samples + k) * 64 + lane, as k_wf_generate lays them out) are
+// tested against them, all lanes on the same triangle (broadcast LDS reads).  Blocks without a list are skipped: k_wf_generate put their
+// segments on a queue of their own for k_wf_trace.
 template <bool COUNT>
 __global__ __launch_bounds__(WAVE) void k_wf_trace_camera(DevScene sc, rt::WfBuffers wb, uint32_t n_samples) {
     extern __shared__ uint4 s_cam[]; // RT_BEAM_CAP * 3 quads + RT_BEAM_CAP floats (+ a per-lane walk stack behind them for the development probe)
