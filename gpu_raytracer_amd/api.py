@@ -26,6 +26,7 @@ FLAG_KERNEL_PIPELINE = 32
 FLAG_NO_BEAMS = 64
 FLAG_STAGE_TIMES = 128
 PREPARE_SHADOW_GRIDS = 1
+PREPARE_QUALITY_TREE = 2
 EXTENDED_AVAILABLE = True
 
 # every symbol include/rt_hip.h declares
@@ -134,7 +135,8 @@ class Context:
         self._check(self.lib.rt_upload_textures(self._h, _p(ti), C.c_uint32(len(ti)), _p(td), C.c_size_t(td.size)))
 
     def prepare(self, what=PREPARE_SHADOW_GRIDS):
-        """rt_prepare: build ahead of time what the first extended-mode frame would otherwise build (the light grids)."""
+        """rt_prepare: build ahead of time what the first extended-mode frame would otherwise build (PREPARE_SHADOW_GRIDS: the light grids), and /
+        or rebuild the tree with the host builder for a scene that stays (PREPARE_QUALITY_TREE)."""
         self._check(self.lib.rt_prepare(self._h, C.c_uint32(what)))
 
     # -- rendering -------------------------------------------------------------------

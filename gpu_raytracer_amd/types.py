@@ -66,12 +66,13 @@ STATS = np.dtype([
     ("kernel_ms", np.float64), ("wall_ms", np.float64),
     ("node_bytes", np.uint64), ("tri_bytes", np.uint64), ("scene_bytes", np.uint64),
     ("bvh_nodes", u32), ("bvh_depth", u32), ("n_devices", u32), ("flags", u32),
-    ("texture_bytes", np.uint64), ("n_textures", u32), ("_pad", u32),
+    ("texture_bytes", np.uint64), ("n_textures", u32), ("tree_build", u32),
     ("grid_bytes", np.uint64), ("grid_build_ms", np.float64),
 ])
 STAT_MEGAKERNEL_FALLBACK = 1
 STAT_SINGLE_PASS = 2
 PREPARE_SHADOW_GRIDS = 1
+PREPARE_QUALITY_TREE = 2
 MAX_BOUNCES = 255
 
 EXPECTED_SIZES = {

@@ -55,3 +55,31 @@ def test_prepare_builds_them_ahead_of_time(gpu_ctx):
     assert st["grid_bytes"] > 0 and gpu_ctx.debug_shadow_grid()["lights_with_grid"] == 1
     gpu_ctx.prepare()  # idempotent
     assert gpu_ctx.stats()["grid_bytes"] == st["grid_bytes"] and gpu_ctx.stats()["grid_build_ms"] == st["grid_build_ms"]
+
+
+def test_quality_tree_is_an_option_for_scenes_that_stay(gpu_ctx, rt_api):
+    """rt_prepare(RT_PREPARE_QUALITY_TREE): the host builder's tree (binned SAH + insertion-based optimisation) in place of the one
+    rt_upload_scene built on the device: same frames in every mode, rt_stats.tree_build says which tree is in use, the light grids
+    (they hold triangle records in leaf order) go with the old tree and come back on demand."""
+    sc = scenes.sponza_like()
+    gpu_ctx.upload_scene(sc)
+    assert gpu_ctx.stats()["tree_build"] == 2  # built on the device
+    frames = {}
+    for mode, kw in ((1, {}), (2, dict(spp=3, max_bounces=3))):
+        gpu_ctx.render(640, 360, sc.camera, mode=mode, **kw)
+        frames[mode] = gpu_ctx.read_rgb32f().copy()
+    before = gpu_ctx.stats()
+    assert before["grid_bytes"] > 0
+    gpu_ctx.prepare(rt_api.PREPARE_QUALITY_TREE)
+    st = gpu_ctx.stats()
+    assert st["tree_build"] == 0 and st["grid_bytes"] == 0 and st["bvh_nodes"] > 0 and st["bvh_nodes"] != before["bvh_nodes"]
+    chk = gpu_ctx.debug_check_bvh()
+    assert chk["failures"] == 0 and chk["placed_once"] == sc.n_triangles and chk["method"] == 0
+    for mode, kw in ((1, {}), (2, dict(spp=3, max_bounces=3))):
+        gpu_ctx.render(640, 360, sc.camera, mode=mode, **kw)
+        np.testing.assert_array_equal(gpu_ctx.read_rgb32f().view(np.uint32), frames[mode].view(np.uint32))
+    assert gpu_ctx.stats()["grid_bytes"] > 0  # rebuilt by the mode-2 frame
+    gpu_ctx.prepare(rt_api.PREPARE_QUALITY_TREE | rt_api.PREPARE_SHADOW_GRIDS)  # idempotent
+    assert gpu_ctx.stats()["tree_build"] == 0
+    gpu_ctx.upload_scene(sc)  # a new upload is a device build again
+    assert gpu_ctx.stats()["tree_build"] == 2
