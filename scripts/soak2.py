@@ -7,7 +7,7 @@ os.environ["RT_WF_TARGET_PATHS"] = "300000"  # many small batches
 import numpy as np
 from gpu_raytracer_amd import api, scenes
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 180.0
-rng = np.random.default_rng(777)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 777)
 t_end = time.time() + budget
 it = bad = 0
 with api.Context() as ctx:

@@ -7,7 +7,7 @@ import numpy as np, oracle
 from gpu_raytracer_amd import api, scenes
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
 n_dev = int(sys.argv[2]) if len(sys.argv) > 2 else 1  # > 1: one context over GPU 0 listed that many times
-rng = np.random.default_rng(12345)
+rng = np.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else 12345)
 scene_list = [scenes.sponza_like(), scenes.random_soup(5000, seed=4, size=0.3, n_spheres=2, n_lights=5), scenes.cornell12(), scenes.default_scene()]
 t_end = time.time() + budget
 it = bad = 0

@@ -15,7 +15,7 @@ from gpu_raytracer_amd import api, scenes
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 n_dev = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-rng = np.random.default_rng(2024)
+rng = np.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else 2024)
 scene_list = [scenes.default_scene(), scenes.cornell12(), scenes.random_soup(300, seed=9, size=0.5, n_spheres=2, n_lights=2), scenes.empty_scene()]
 packs = [oracle.PackedScene(s, use_bvh=False) for s in scene_list]  # brute force: ties resolve to the lowest index
 t_end = time.time() + budget
