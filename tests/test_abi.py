@@ -82,8 +82,8 @@ def test_python_flag_values_are_the_headers(rt_api):
         py = name[3:]  # RT_FLAG_X -> FLAG_X
         if hasattr(rt_api, py):
             assert getattr(rt_api, py) == value, name
-    for flag in ("FLAG_COUNTERS", "FLAG_NO_SHADOWS", "FLAG_KERNEL_V1", "FLAG_KERNEL_SM", "FLAG_NO_SHADOW_GRID", "FLAG_KERNEL_PIPELINE"):
+    for flag in ("FLAG_COUNTERS", "FLAG_NO_SHADOWS", "FLAG_KERNEL_V1", "FLAG_KERNEL_SM", "FLAG_NO_SHADOW_GRID", "FLAG_KERNEL_PIPELINE", "FLAG_NO_BEAMS", "FLAG_STAGE_TIMES"):
         assert "RT_" + flag in defines and hasattr(rt_api, flag), flag
     lib = rt_api.load()
-    for sym in ("rt_debug_shadow_grid", "rt_debug_counters", "rt_debug_check_bvh"):
+    for sym in ("rt_debug_shadow_grid", "rt_debug_counters", "rt_debug_check_bvh", "rt_debug_stage_times", "rt_debug_beams"):
         assert hasattr(lib, sym), sym

@@ -83,3 +83,17 @@ def test_quality_tree_is_an_option_for_scenes_that_stay(gpu_ctx, rt_api):
     assert gpu_ctx.stats()["tree_build"] == 0
     gpu_ctx.upload_scene(sc)  # a new upload is a device build again
     assert gpu_ctx.stats()["tree_build"] == 2
+
+
+def test_stage_times_are_those_of_the_light_grid_launches(gpu_ctx):
+    """RT_FLAG_STAGE_TIMES (bench.py's roofline of the dominant kernel): every k_wf_shadow_grid launch of the frame is timed with HIP events on
+    the stream it is launched on: one launch per batch and depth, their sum a part of the frame's kernel time; frames without the flag report none."""
+    sc = scenes.sponza_like()
+    gpu_ctx.upload_scene(sc)
+    st = gpu_ctx.render(640, 360, sc.camera, mode=2, spp=4, max_bounces=3, stage_times=True)
+    ms, launches = gpu_ctx.debug_stage_times()
+    assert launches in (4, 8) and 0.0 < ms < st["kernel_ms"]  # (3 + 1) depths x one or two batches
+    gpu_ctx.render(640, 360, sc.camera, mode=2, spp=4, max_bounces=3)
+    assert gpu_ctx.debug_stage_times() == (0.0, 0)
+    gpu_ctx.render(640, 360, sc.camera, mode=2, spp=4, max_bounces=3, stage_times=True, no_shadow_grid=True)
+    assert gpu_ctx.debug_stage_times() == (0.0, 0)  # no light-grid launches in that frame
