@@ -783,7 +783,8 @@ __device__ __forceinline__ DevMaterial load_material(const DevScene& sc, uint32_
 static_assert(EXT_EPS == RT_SG_EXT_EPS, "the light grids' dilation is derived from the shadow segments' origin offset");
 static_assert(RT_WF_GRID_WALK < RT_SG_SORTED_PREFIX, "a walk may only look at the ordered part of a list");
 #ifndef RT_WF_GRID_BLOCKS_PER_CU
-#define RT_WF_GRID_BLOCKS_PER_CU 16 /* 256-thread blocks per CU: 8 measured 3 % slower, 4 the same as 8 */
+#define RT_WF_GRID_BLOCKS_PER_CU 32 /* 256-thread blocks per CU in the grid-stride launch: 8 measured 3 % slower than 16 (round 2); 32 / 48 / 64: -0.7 % / -0.6 % / -0.6 % on the
+                                        headline frame, an eighth of it +0.4 % / +2 % / +2 % (round 3, profiles/ab_r03.json) */
 #endif
 #ifndef RT_WF_GRID_MIN_WAVES
 #define RT_WF_GRID_MIN_WAVES 7 /* waves per SIMD the list walk is register-allocated for: 8 (64 VGPRs) spills five registers inside its loop - scratch
