@@ -44,6 +44,9 @@ using namespace rtdev;
 #ifndef RT_WF_WAVES_PER_CU
 #define RT_WF_WAVES_PER_CU 24
 #endif
+#ifndef RT_WF_WAVES_SMALL
+#define RT_WF_WAVES_SMALL 12u /* of RT_WF_WAVES_PER_CU: what a launch over a batch below 24 Mi path slots uses: fewer, longer-lived waves drain a short queue with less tail (ab_r03: waves_per_cu_by_batch) */
+#endif
 #ifndef RT_WF_SHADOW_LIGHT_MAJOR
 #define RT_WF_SHADOW_LIGHT_MAJOR 1
 #endif
@@ -1278,7 +1281,17 @@ size_t wf_queue_slots_for(size_t max_entries, uint32_t per_lane, size_t waves) {
 }
 size_t wf_queue_slots(size_t max_entries, uint32_t per_lane) { return wf_queue_slots_for(max_entries, per_lane, (size_t)wf_shading_blocks() * 4); }
 uint32_t wf_pick_window(uint32_t iters, uint32_t per_lane) { return pick_window(iters, per_lane); }
-uint32_t wf_persistent_waves() { return (uint32_t)(cu_count() * RT_WF_WAVES_PER_CU); }
+uint32_t wf_persistent_waves() { return (uint32_t)(cu_count() * RT_WF_WAVES_PER_CU); } // the most a launch uses (what the stacks' overflow area is sized for)
+// Waves per CU of one traversal launch, from the path slots of the batch it serves (round 3, profiles/ab_r03.json: waves_per_cu_by_batch): the
+// fewer segments a launch has, the more its end - waves finishing their last chunk one by one - weighs, and the shorter that end is with
+// fewer, busier waves.  An eighth of the headline frame (8 M path slots per batch) is 3.5 % faster with 10-12 waves per CU than with 24
+// (23.9 against 24.8 ms), a quarter is level (42.6 ms either way; 16 and 20 are slower), the whole frame (33 M per batch) wants all 24
+// (166.2 against 167.6 with 20, 170.2 with 18).
+static uint32_t trace_waves_per_cu(uint32_t path_slots) {
+    static const int forced = [] { const char* e = std::getenv("RT_WF_WAVES_PER_CU"); const int v = e ? std::atoi(e) : 0; return v > 0 && v <= RT_WF_WAVES_PER_CU ? v : 0; }(); // development knob
+    if (forced) return (uint32_t)forced;
+    return path_slots >= (24u << 20) ? (uint32_t)RT_WF_WAVES_PER_CU : RT_WF_WAVES_SMALL;
+}
 
 hipError_t wf_beams(const DevScene& sc, const DevFrame& fr, const WfBuffers& wb, hipStream_t s) {
     if (!wb.beam_count || wb.n_blocks == 0) return hipSuccess;
@@ -1299,7 +1312,7 @@ hipError_t wf_generate(const DevScene&, const DevFrame& fr, const WfBuffers& wb,
 template <bool COUNT, bool ANY>
 static void launch_trace(const DevScene& sc, const WfBuffers& wb, const uint32_t* q, uint32_t count_slot, uint32_t cursor_slot, uint32_t window_slot, hipStream_t s) {
     const size_t lds = (size_t)RT_WF8_LDS_STACK * WAVE * sizeof(uint2) + 2048;
-    hipLaunchKernelGGL((k_wf_trace<COUNT, ANY>), dim3(wf_persistent_waves()), dim3(WAVE), lds, s, sc, wb, q, count_slot, cursor_slot, window_slot);
+    hipLaunchKernelGGL((k_wf_trace<COUNT, ANY>), dim3((uint32_t)cu_count() * trace_waves_per_cu(wb.capacity)), dim3(WAVE), lds, s, sc, wb, q, count_slot, cursor_slot, window_slot);
 }
 
 hipError_t wf_bounce(const DevScene& sc, const DevFrame& fr, const WfBuffers& wb, uint32_t iteration, uint32_t n_samples, bool counters, hipStream_t s, hipEvent_t* grid_events) {
