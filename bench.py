@@ -41,10 +41,14 @@ S_OUT_BYTES = 16 + 12 + 8  # per pixel: RGBA32F + three unorm8 texels + (prim id
 #   extension segment (camera or continuation): written by generate/finish: ray_o, ray_d, thr, rad (64) + queue id (4);
 #     read by the closest-hit walk: id (4) + ray_o, ray_d (32), writes the hit record (16); the shade stage reads
 #     id + hit (20) and writes the vertex record (32); the finish stage reads id + the vertex record, thr, rad, ray_d (84)
-#   shadow segment: queue entry written and read (8) + the vertex record read (32) + one visibility bit (atomicOr, 4)
+#   shadow segment walked through the BVH (no light grids, or handed on by them): queue entry written and read (8) + the vertex record
+#     read (32) + the visibility word's update (atomic, 4)
+#   the light-grid stage goes by vertex, not by segment: per extension segment the queue id (4) + the vertex record (32) read once for
+#     all its lights + the visibility word's update (4)
 #   path: the sample's radiance written once and read once by the resolve (32) + pxy (4)
 S_STATE_EXTENSION = 64 + 4 + 4 + 32 + 16 + 20 + 32 + 84
 S_STATE_SHADOW = 8 + 32 + 4
+S_STATE_SHADOW_VERTEX = 4 + 32 + 4
 S_STATE_PATH = 32 + 4
 
 
@@ -359,7 +363,9 @@ def main():
     wavefront = mode_name == "extended" and args.kernel == "wavefront"
     # (a triangle tested from a light's list is a 48-byte entry instead of a 48-byte record: the same figure; its cell costs 8 bytes more)
     fetch_bytes = stc["node_visits"] * stc["node_bytes"] + stc["tri_tests"] * stc["tri_bytes"] + grid["segments_answered"] * 8
-    state_bytes = (ext_segments * S_STATE_EXTENSION + stc["shadow_rays"] * S_STATE_SHADOW + stc["primary_rays"] * S_STATE_PATH) if wavefront else 0
+    grids_on = wavefront and grid["lights_with_grid"] > 0 and grid["segments_answered"] > 0
+    shadow_state = (ext_segments * S_STATE_SHADOW_VERTEX + (stc["shadow_rays"] - grid["segments_answered"]) * S_STATE_SHADOW) if grids_on else stc["shadow_rays"] * S_STATE_SHADOW
+    state_bytes = (ext_segments * S_STATE_EXTENSION + shadow_state + stc["primary_rays"] * S_STATE_PATH) if wavefront else 0
     # SURVEY §8d's algorithmic bytes: every record fetch + the path state + the pixels.  The scene (23 MB) is cache
     # resident, so most of this never reaches HBM: it is reported as a rate, not as a fraction of the HBM peak.
     alg_bytes = fetch_bytes + state_bytes + stc["pixels"] * S_OUT_BYTES
@@ -384,17 +390,20 @@ def main():
             "hbm_frac": (traffic / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic is not None else None,
             "compulsory_hbm_bytes": compulsory_bytes,
             "algorithmic_bytes": alg_bytes, "algorithmic_GBps": alg_bytes / (avg_kernel_ms * 1e-3) / 1e9,
-            "state_bytes_per_segment": {"extension": S_STATE_EXTENSION, "shadow": S_STATE_SHADOW, "path": S_STATE_PATH} if wavefront else None,
+            "state_bytes_per_segment": {"extension": S_STATE_EXTENSION, "shadow_through_bvh": S_STATE_SHADOW, "light_grid_stage_per_extension_segment": S_STATE_SHADOW_VERTEX,
+                                        "path": S_STATE_PATH} if wavefront else None,
             "nodes_per_ray": stc["node_visits"] / max(stc["rays"], 1), "tris_per_ray": stc["tri_tests"] / max(stc["rays"], 1),
             "note": "algorithmic_*: SURVEY 8d's per-segment figure over every kernel (node fetches x 80 B + triangle fetches x 48 B + per-kind path state + "
                     "pixels x 36 B); ~90 % of it is served by L1/L2 (the scene is 28 MB), so it is a rate, not an HBM fraction",
         }
         dom = prof.get("dominant_kernel") if prof else None
         if wavefront and grid_launches and grid["lights_with_grid"]:
-            # SURVEY 8d / DESIGN 4 for the dominant kernel k_wf_shadow_grid, per launch: every shadow segment reads its queue entry and vertex and
-            # sets one visibility bit (44 B), every answered one reads its cell's header (8 B) and 48 B per list entry it looks at
+            # SURVEY 8d / DESIGN 4 for the dominant kernel k_wf_shadow_grid, per launch: every extension segment's queue id and vertex record are
+            # read once and its visibility word updated (40 B), every segment the lists answer reads its cell's header (8 B) and 48 B per list
+            # entry it looks at, every segment handed on is written to the next queue (4 B)
             launches_per_frame = grid_launches / 2.0
-            alg_grid = (grid["entries_read"] * 48 + grid["segments_answered"] * 8 + stc["shadow_rays"] * S_STATE_SHADOW) / launches_per_frame
+            alg_grid = (grid["entries_read"] * 48 + grid["segments_answered"] * 8 + ext_segments * S_STATE_SHADOW_VERTEX +
+                        (stc["shadow_rays"] - grid["segments_answered"]) * 4) / launches_per_frame
             launch_ms = grid_ms / grid_launches
             achieved = alg_grid / (launch_ms * 1e-3) / 1e9
             dom_traffic = dom.get("hbm_bytes_per_launch") if dom and dom.get("name") == "k_wf_shadow_grid" else None
@@ -406,9 +415,10 @@ def main():
                 "achieved_source": "algorithmic bytes per launch (counting variant of the same kernels, this run) / average duration of the kernel's launches, HIP events on "
                                    "their stream, frames on one lane (this run); traffic: FETCH_SIZE x 1 + WRITE_SIZE of the committed PMC passes of this build - its reads are "
                                    "scattered 16-byte quads, for which FETCH_SIZE counts requests of 64 bytes (profiles/r03_fetch_calibration.json)",
-                "practical_bound": "the rate of scattered memory requests: every segment is a chain queue entry -> vertex -> cell block -> (further entries), ~1.8 L2 misses; "
-                                   "fewer requests per segment (packed cell blocks) and more requests in flight (prefetching the chain's head) both measured no faster "
-                                   "(profiles/ab_r03.json)",
+                "practical_bound": "the rate of scattered memory requests (33 G/s of 64 bytes against 24-43 G/s that a bare gather loop sustains, profiles/r03_fetch_calibration.json): "
+                                   "every segment costs its cell's block and 0.5 further entries, none of it shared between neighbouring lanes beyond depth 0; fewer requests "
+                                   "per segment (packed cell blocks), more requests in flight (the next light's block fetched while this one's is looked at) and more waves "
+                                   "all measured no faster (profiles/ab_r03.json)",
                 "read_requests_per_s": dom.get("read_requests_per_s") if dom else None,
                 "shadow_grids": {"lights_with_grid": grid["lights_with_grid"], "bytes": grid["bytes"], "entries": grid["entries"],
                                  "shadow_segments_answered_share": grid["segments_answered"] / max(stc["shadow_rays"], 1),

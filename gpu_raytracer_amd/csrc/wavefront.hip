@@ -418,7 +418,7 @@ __global__ __launch_bounds__(WAVE, RT_WF8_MIN_WAVES) void k_wf_trace(DevScene sc
             if (active && busy == 0u) { // segment finished
                 second = false;
                 if (ANY) {
-                    if (hit.prim == RT_PRIM_MISS) atomicOr(reinterpret_cast<uint32_t*>(&wb.vtx[2 * (size_t)id + 1]) + 3, 1u << li);
+                    if (hit.prim != RT_PRIM_MISS) atomicAnd(reinterpret_cast<uint32_t*>(&wb.vtx[2 * (size_t)id + 1]) + 3, ~(1u << li)); // occluded: the light leaves the visibility word (k_wf_shade set it)
                 } else {
                     const V3 hp = o + d * hit.t;
                     const uint32_t code = hit.prim == RT_PRIM_MISS ? RT_PRIM_MISS : ((hit.prim & RT_PRIM_SPHERE_FLAG) ? hit.prim : hit.slot);
@@ -771,17 +771,16 @@ __device__ __forceinline__ DevMaterial load_material(const DevScene& sc, uint32_
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// shadow segments through the per-light grids (shadow_grid.h).  One thread per queue entry, no refill machinery: the work of a
-// segment is a short dependent chain of fetches (vertex -> cell -> list entry -> triangle record; measured 2.4 entries per
-// segment on the headline scene), so what counts is the number of segments in flight, not lane utilisation - a persistent
-// version with k_wf_trace's refill was latency-bound at a twelfth of the VALU rate and slower than the traversal it replaces.
-// A lane walks its cell's list nearest to the light first until the reference's triangle test accepts one (occluded) or the keys
-// pass the segment's own end (visible).  Segments that are
-// still undecided after RT_WF_GRID_WALK entries, segments in cells longer than the grid's `heavy` and segments of lights without
-// a grid are appended, densely, to q_shadow2 for k_wf_trace<any hit>.
+// shadow segments through the per-light grids (shadow_grid.h).  One thread per vertex, no refill machinery: the work of a segment is a
+// short dependent chain of fetches (cell block -> further list entries; measured 2.2 entries per segment on the headline scene), so what
+// counts is the number of segments in flight - a persistent version with k_wf_trace's refill was latency-bound at a twelfth of the VALU
+// rate and slower than the traversal it replaces.  A segment goes through its cell's list nearest to the light first until the
+// reference's triangle test accepts an entry (occluded) or the keys pass the segment's own end (visible).  Segments that are still
+// undecided after RT_WF_GRID_WALK entries, segments in cells longer than the grid's `heavy` and segments of lights without a grid are
+// appended, densely, to q_shadow2 for k_wf_trace<any hit>.
 // ---------------------------------------------------------------------------------------------------------
 #ifndef RT_WF_GRID_WALK
-#define RT_WF_GRID_WALK 12
+#define RT_WF_GRID_WALK 15 /* entries a segment looks at before it is handed on (12 while a long walk held its whole wave up: rounds 2-3) */
 #endif
 static_assert(EXT_EPS == RT_SG_EXT_EPS, "the light grids' dilation is derived from the shadow segments' origin offset");
 static_assert(RT_WF_GRID_WALK < RT_SG_SORTED_PREFIX, "a walk may only look at the ordered part of a list");
@@ -793,14 +792,154 @@ static_assert(RT_WF_GRID_WALK < RT_SG_SORTED_PREFIX, "a walk may only look at th
 #define RT_WF_GRID_MIN_WAVES 7 /* waves per SIMD the list walk is register-allocated for: 8 (64 VGPRs) spills five registers inside its loop - scratch
                                 traffic in a stage bound by memory requests; 7 (72 VGPRs): -2.7 % on the headline frame, 6 the same (profiles/ab_r03.json) */
 #endif
+// One shadow segment (vertex `point` / `normal` toward light li) against the head of its cell's list: what the cell's own 128-byte block
+// holds (header, two entries, the key of the third).  Outcome GRID_VISIBLE / GRID_OCCLUDED / GRID_FORWARD (left to the BVH), or
+// GRID_PENDING: the list goes on beyond the block and the segment has not met its occluder or its end yet - `pend` is then what the
+// second part of the walk (grid_walk_on) needs.
+enum : uint32_t { GRID_VISIBLE = 0u, GRID_OCCLUDED = 1u, GRID_FORWARD = 2u, GRID_PENDING = 3u };
+struct GridPending {
+    V3 o, d;
+    float dist, limit;
+    uint32_t at;    // the next entry, as an index into the grid's overflow array
+    uint32_t i, count; // ... which is entry i of `count`
+};
+static_assert(RT_SG_BLOCK_ENTRIES == 2u, "grid_segment_head tests the block's two entries by name");
 template <bool COUNT>
-__global__ __launch_bounds__(256, RT_WF_GRID_MIN_WAVES) void k_wf_shadow_grid(DevScene sc, rt::WfBuffers wb) {
+__device__ __forceinline__ uint32_t grid_segment_head(const DevScene& sc, const DevLight& light, const DevShadowGrid& g, V3 point, V3 normal, GridPending& pend,
+                                                      uint32_t& n_tests, uint32_t& n_entries) {
+    V3 d;
+    float dist;
+    shadow_segment(light, point, d, dist);
+    const V3 o = point + normal * EXT_EPS;
+    Hit hit;
+    hit.t = dist;
+    hit.prim = RT_PRIM_MISS;
+    hit.slot = 0;
+    test_spheres(sc, o, d, hit);
+    if (hit.prim != RT_PRIM_MISS) return GRID_OCCLUDED; // by a sphere: nothing left to do
+    const uint32_t kind = g.kind;
+    uint32_t cell = 0xFFFFFFFFu; // no cell: an empty list
+    float limit = 0.0f;
+    if (kind == RT_SG_KIND_CUBE) {
+        // the direction from the light toward the vertex picks the face (largest component) and the cell (the other two over it)
+        const float wx = -d.x, wy = -d.y, wz = -d.z;
+        const float ax = fabsf(wx), ay = fabsf(wy), az = fabsf(wz);
+        const uint32_t a = (ax >= ay && ax >= az) ? 0u : (ay >= az ? 1u : 2u);
+        const float wa = a == 0u ? wx : (a == 1u ? wy : wz), wb_ = a == 0u ? wy : (a == 1u ? wz : wx), wc = a == 0u ? wz : (a == 1u ? wx : wy);
+        const float inv = __builtin_amdgcn_rcpf(fabsf(wa)); // (an ulp either way is far inside the lists' margin)
+        const float fu = (wb_ * inv + 1.0f) * g.scale, fv = (wc * inv + 1.0f) * g.scale;
+        const uint32_t top = g.res - 1u;
+        const uint32_t ix = min((uint32_t)max((int)floorf(fu), 0), top), iy = min((uint32_t)max((int)floorf(fv), 0), top);
+        cell = ((2u * a + (wa < 0.0f ? 1u : 0u)) * g.res + iy) * g.res + ix;
+        limit = dist + g.limit_margin;
+    } else if (kind == RT_SG_KIND_ORTHO) {
+        const float fu = (dot(o, ld3(g.axis_u)) - g.u0) * g.scale, fv = (dot(o, ld3(g.axis_v)) - g.v0) * g.scale;
+        const float r = (float)g.res;
+        if (fu >= 0.0f && fu < r && fv >= 0.0f && fv < r) cell = (uint32_t)fv * g.res + (uint32_t)fu; // outside: nothing projects there
+        limit = (g.key_top - dot(o, ld3(g.axis_w))) + g.limit_margin;
+    } else {
+        return GRID_FORWARD; // a light without a grid
+    }
+    // the cell's block: header and the list's first entry in the first half of its 128-byte line, the second entry in the other half
+    if (cell == 0xFFFFFFFFu && g.near_begin == g.near_end) return GRID_VISIBLE;
+    uint4 hd = make_uint4(0u, 0u, 0x7F800000u, 0u), q0 = hd, q1 = hd, q2 = hd;
+    const uint4* __restrict__ blk = g.blocks + (size_t)(cell == 0xFFFFFFFFu ? 0u : cell) * RT_SG_BLOCK_QUADS;
+    if (cell != 0xFFFFFFFFu) {
+        hd = blk[0];
+        q0 = blk[1], q1 = blk[2], q2 = blk[3];
+        RT_KEEP4(hd);
+        RT_KEEP4(q0);
+        RT_KEEP4(q1);
+        RT_KEEP4(q2);
+    }
+    const uint32_t count = hd.x;
+    if (count > g.heavy) return GRID_FORWARD;
+    const uint4* __restrict__ ovf = g.overflow; // 48-byte entries: {key, v0} {e1, e2.x} {e2.yz, record, 0}
+    // triangles too close to the light for a bounded dilation: tested by every segment of the light (normally none)
+    for (uint32_t k = g.near_begin; k < g.near_end; k++) {
+        const uint4 n0 = ovf[3 * (size_t)k], n1 = ovf[3 * (size_t)k + 1], n2 = ovf[3 * (size_t)k + 2];
+        if (COUNT) n_tests++;
+        float t;
+        if (moller_trumbore(v3(__uint_as_float(n0.y), __uint_as_float(n0.z), __uint_as_float(n0.w)), v3(__uint_as_float(n1.x), __uint_as_float(n1.y), __uint_as_float(n1.z)),
+                            v3(__uint_as_float(n1.w), __uint_as_float(n2.x), __uint_as_float(n2.y)), o, d, t) &&
+            t > RT_MIN_RAY_DISTANCE && t < dist)
+            return GRID_OCCLUDED;
+    }
+    // entries come nearest to the light first: a key beyond the segment's own end means every later triangle lies beyond it too
+    if (count == 0u || !(__uint_as_float(q0.x) < limit)) return GRID_VISIBLE;
+    float t;
+    if (COUNT) n_entries++, n_tests++;
+    // the acceptance of test_triangle for a segment that has hit nothing yet: 1e-5 < t < its length
+    if (moller_trumbore(v3(__uint_as_float(q0.y), __uint_as_float(q0.z), __uint_as_float(q0.w)), v3(__uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z)),
+                        v3(__uint_as_float(q1.w), __uint_as_float(q2.x), __uint_as_float(q2.y)), o, d, t) &&
+        t > RT_MIN_RAY_DISTANCE && t < dist)
+        return GRID_OCCLUDED;
+    if (count == 1u) return GRID_VISIBLE;
+    q0 = blk[4], q1 = blk[5], q2 = blk[6];
+    if (!(__uint_as_float(q0.x) < limit)) return GRID_VISIBLE;
+    if (COUNT) n_entries++, n_tests++;
+    if (moller_trumbore(v3(__uint_as_float(q0.y), __uint_as_float(q0.z), __uint_as_float(q0.w)), v3(__uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z)),
+                        v3(__uint_as_float(q1.w), __uint_as_float(q2.x), __uint_as_float(q2.y)), o, d, t) &&
+        t > RT_MIN_RAY_DISTANCE && t < dist)
+        return GRID_OCCLUDED;
+    if (count == 2u || !(__uint_as_float(hd.z) < limit)) return GRID_VISIBLE; // (the third entry's key travels in the header)
+    pend.o = o, pend.d = d, pend.dist = dist, pend.limit = limit;
+    pend.at = hd.y, pend.i = 2u, pend.count = count;
+    return GRID_PENDING;
+}
+// ... and the list beyond the block, at most `trips` entries further: entries 2, 3, ... follow each other in the overflow array, each is
+// fetched when the one before it has decided nothing.  GRID_PENDING again: `pend` has moved on.
+template <bool COUNT>
+__device__ __forceinline__ uint32_t grid_walk_on(const DevShadowGrid& g, GridPending& pend, uint32_t trips, uint32_t& n_tests, uint32_t& n_entries) {
+    const uint4* __restrict__ ovf = g.overflow;
+    for (uint32_t k = 0; k < trips; k++) {
+        const size_t at = 3 * (size_t)pend.at;
+        uint4 q0 = ovf[at], q1 = ovf[at + 1], q2 = ovf[at + 2];
+        RT_KEEP4(q0);
+        RT_KEEP4(q1);
+        RT_KEEP4(q2);
+        if (!(__uint_as_float(q0.x) < pend.limit)) return GRID_VISIBLE;
+        if (COUNT) n_entries++, n_tests++;
+        float t;
+        if (moller_trumbore(v3(__uint_as_float(q0.y), __uint_as_float(q0.z), __uint_as_float(q0.w)), v3(__uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z)),
+                            v3(__uint_as_float(q1.w), __uint_as_float(q2.x), __uint_as_float(q2.y)), pend.o, pend.d, t) &&
+            t > RT_MIN_RAY_DISTANCE && t < pend.dist)
+            return GRID_OCCLUDED;
+        pend.at++;
+        pend.i++;
+        if (pend.i >= pend.count) return GRID_VISIBLE;
+        if (pend.i >= RT_WF_GRID_WALK) return GRID_FORWARD;
+    }
+    return GRID_PENDING;
+}
+
+// One thread per vertex of the bounce (the entries of the extension queue, as k_wf_shade and k_wf_finish read it); k_wf_shade has left the
+// lights that need a segment as the vertex record's visibility word, and what this stage (and k_wf_trace<any hit> after it) does is CLEAR
+// the bits of occluded segments - every update of the word is an atomic and-not, so their order does not matter.  The wave goes through the
+// lights together - neighbouring vertices toward one light fall into neighbouring cells - and a lane skips the lights it has no segment for.
+// Against one thread per (vertex, light) entry of a shadow queue (rounds 1-2): the 32-byte vertex record is read once instead of once per
+// light, and the queue (4 bytes written and read per segment) is gone.
+//
+// List walks differ in length (headline scene: 2.2 entries on average, but 22 % of the segments need more than the two entries of their
+// cell's block, 9 % more than four, 2 % more than nine - so that nearly every wave of 64 had a lane going to the walk's limit, the others
+// idle behind it: a fifth of the lanes at work, and each trip a dependent fetch the whole wave waits for).  So a lane only looks at its
+// cell's block; a segment undecided after that is parked in the wave's list in LDS (44 bytes), and when 64 are parked the wave walks them
+// on together, RT_WF_GRID_PASS entries at a time, parking again what is still undecided.
+#ifndef RT_WF_GRID_PASS
+#define RT_WF_GRID_PASS 3u
+#endif
+#define RT_WF_GRID_PARK 128u /* slots of a wave's list: fewer than 64 parked before a light's segments add at most 64 */
+#define RT_WF_GRID_PARK_WORDS 11u
+template <bool COUNT>
+__global__ __launch_bounds__(256, RT_WF_GRID_MIN_WAVES) void k_wf_shadow_grid(DevScene sc, rt::WfBuffers wb, const uint32_t* __restrict__ queue) {
     __shared__ DevLight s_lights[RT_WF_MAX_LIGHTS];
     __shared__ DevShadowGrid s_grids[RT_WF_MAX_LIGHTS];
     __shared__ uint32_t s_fwd[4][128]; // per wave: entries to hand on, not yet appended
+    __shared__ uint32_t s_park[4][RT_WF_GRID_PARK_WORDS][RT_WF_GRID_PARK];
     if (wb.totals[WF_TOTAL_ERROR] != 0ull) return;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t n_fwd = 0; // (wave-uniform)
+    const unsigned long long below = (1ull << lane) - 1ull;
+    uint32_t n_fwd = 0, n_park = 0; // (wave-uniform)
     stage_lights(s_lights, sc);
     {
         const uint32_t words = sc.n_lights * (uint32_t)(sizeof(DevShadowGrid) / 4);
@@ -809,148 +948,95 @@ __global__ __launch_bounds__(256, RT_WF_GRID_MIN_WAVES) void k_wf_shadow_grid(De
         for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
         __syncthreads();
     }
-    const uint32_t* __restrict__ queue = wb.q_shadow;
-    const uint32_t count = wb.counters[rt::WF_SHADOW_COUNT]; // slots, window padding (sentinels) included
-    const uint32_t stride = gridDim.x * blockDim.x;
     uint32_t n_tests = 0, n_entries = 0, n_answered = 0;
-    for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += stride) { // (block-uniform bound: the append below is a wave operation)
-        const uint32_t i = base + threadIdx.x;
-        const uint32_t e = i < count ? queue[i] : WF_SENTINEL;
-        bool forward = false;
-        if (e != WF_SENTINEL) {
-            const uint32_t id = e & RT_WF_ID_MASK, li = e >> 27;
+    uint32_t(*park)[RT_WF_GRID_PARK] = s_park[wave];
+    // hand on: collected per wave in LDS and appended 64 or more at a time (one atomic on the queue's counter per append: an atomic per
+    // wave and iteration, 1.5 M of them on one address, cost more than the whole list walk)
+    auto hand_on = [&](bool forward, uint32_t entry, bool flush) {
+        const unsigned long long fm = __ballot(forward);
+        if (fm != 0ull) {
+            if (forward) s_fwd[wave][n_fwd + (uint32_t)__popcll(fm & below)] = entry;
+            n_fwd += (uint32_t)__popcll(fm);
+        }
+        if (n_fwd >= 64u || (flush && n_fwd)) {
+            uint32_t at = 0;
+            if (lane == 0) at = atomicAdd(&wb.counters[rt::WF_SHADOW2_COUNT], n_fwd);
+            at = __shfl(at, 0, WAVE);
+            for (uint32_t k = lane; k < n_fwd; k += WAVE) wb.q_shadow2[at + k] = s_fwd[wave][k];
+            n_fwd = 0;
+        }
+    };
+    auto park_push = [&](bool pending, const GridPending& pd, uint32_t entry) {
+        const unsigned long long pm = __ballot(pending);
+        if (pm == 0ull) return;
+        if (pending) {
+            const uint32_t s = n_park + (uint32_t)__popcll(pm & below);
+            park[0][s] = __float_as_uint(pd.o.x), park[1][s] = __float_as_uint(pd.o.y), park[2][s] = __float_as_uint(pd.o.z);
+            park[3][s] = __float_as_uint(pd.d.x), park[4][s] = __float_as_uint(pd.d.y), park[5][s] = __float_as_uint(pd.d.z);
+            park[6][s] = __float_as_uint(pd.dist), park[7][s] = __float_as_uint(pd.limit);
+            park[8][s] = pd.at, park[9][s] = pd.i | (pd.count << 8), park[10][s] = entry;
+        }
+        n_park += (uint32_t)__popcll(pm);
+    };
+    // the parked segments on top of the list (64, or all of them), RT_WF_GRID_PASS entries further
+    auto walk_parked = [&]() {
+        const uint32_t take = min(n_park, 64u), first = n_park - take;
+        const bool have = lane < take;
+        GridPending pd = {};
+        uint32_t entry = 0, outcome = GRID_VISIBLE;
+        if (have) {
+            const uint32_t s = first + lane;
+            pd.o = v3(__uint_as_float(park[0][s]), __uint_as_float(park[1][s]), __uint_as_float(park[2][s]));
+            pd.d = v3(__uint_as_float(park[3][s]), __uint_as_float(park[4][s]), __uint_as_float(park[5][s]));
+            pd.dist = __uint_as_float(park[6][s]), pd.limit = __uint_as_float(park[7][s]);
+            pd.at = park[8][s];
+            const uint32_t ic = park[9][s];
+            pd.i = ic & 0xFFu, pd.count = ic >> 8;
+            entry = park[10][s];
+            outcome = grid_walk_on<COUNT>(s_grids[entry >> 27], pd, RT_WF_GRID_PASS, n_tests, n_entries);
+            if (outcome == GRID_OCCLUDED) atomicAnd(reinterpret_cast<uint32_t*>(&wb.vtx[2 * (size_t)(entry & RT_WF_ID_MASK) + 1]) + 3, ~(1u << (entry >> 27)));
+            if (COUNT && outcome <= GRID_OCCLUDED) n_answered++;
+        }
+        n_park = first;
+        park_push(have && outcome == GRID_PENDING, pd, entry);
+        hand_on(have && outcome == GRID_FORWARD, entry, false);
+    };
+    const uint32_t count = wb.counters[rt::WF_EXT_COUNT]; // slots, window padding (sentinels) included
+    const uint32_t stride = gridDim.x * blockDim.x;
+    uint32_t id_next = blockIdx.x * blockDim.x + threadIdx.x < count ? queue[blockIdx.x * blockDim.x + threadIdx.x] : WF_SENTINEL;
+    for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += stride) { // (block-uniform bound: the appends are wave operations)
+        const uint32_t id = id_next;
+        const uint32_t i_next = base + stride + threadIdx.x; // the next entry is fetched a whole iteration ahead
+        id_next = i_next < count ? queue[i_next] : WF_SENTINEL;
+        uint32_t want = 0;
+        V3 point = v3(0, 0, 0), normal = point;
+        if (id != WF_SENTINEL) {
             float4 vp = wb.vtx[2 * (size_t)id], vn = wb.vtx[2 * (size_t)id + 1];
             RT_KEEP4(vp);
             RT_KEEP4(vn);
-            const V3 point = f4v(vp), normal = f4v(vn);
-            V3 d;
-            float dist;
-            shadow_segment(s_lights[li], point, d, dist);
-            const V3 o = point + normal * EXT_EPS;
-            Hit hit;
-            hit.t = dist;
-            hit.prim = RT_PRIM_MISS;
-            hit.slot = 0;
-            test_spheres(sc, o, d, hit);
-            if (hit.prim == RT_PRIM_MISS) { // (occluded by a sphere: nothing left to do)
-                const DevShadowGrid& g = s_grids[li];
-                const uint32_t kind = g.kind;
-                uint32_t cell = 0xFFFFFFFFu; // no cell: an empty list
-                float limit = 0.0f;
-                if (kind == RT_SG_KIND_CUBE) {
-                    // the direction from the light toward the vertex picks the face (largest component) and the cell (the other two over it)
-                    const float wx = -d.x, wy = -d.y, wz = -d.z;
-                    const float ax = fabsf(wx), ay = fabsf(wy), az = fabsf(wz);
-                    const uint32_t a = (ax >= ay && ax >= az) ? 0u : (ay >= az ? 1u : 2u);
-                    const float wa = a == 0u ? wx : (a == 1u ? wy : wz), wb_ = a == 0u ? wy : (a == 1u ? wz : wx), wc = a == 0u ? wz : (a == 1u ? wx : wy);
-                    const float inv = __builtin_amdgcn_rcpf(fabsf(wa)); // (an ulp either way is far inside the lists' margin)
-                    const float fu = (wb_ * inv + 1.0f) * g.scale, fv = (wc * inv + 1.0f) * g.scale;
-                    const uint32_t top = g.res - 1u;
-                    const uint32_t ix = min((uint32_t)max((int)floorf(fu), 0), top), iy = min((uint32_t)max((int)floorf(fv), 0), top);
-                    cell = ((2u * a + (wa < 0.0f ? 1u : 0u)) * g.res + iy) * g.res + ix;
-                    limit = dist + g.limit_margin;
-                } else if (kind == RT_SG_KIND_ORTHO) {
-                    const float fu = (dot(o, ld3(g.axis_u)) - g.u0) * g.scale, fv = (dot(o, ld3(g.axis_v)) - g.v0) * g.scale;
-                    const float r = (float)g.res;
-                    if (fu >= 0.0f && fu < r && fv >= 0.0f && fv < r) cell = (uint32_t)fv * g.res + (uint32_t)fu; // outside: nothing projects there
-                    limit = (g.key_top - dot(o, ld3(g.axis_w))) + g.limit_margin;
-                } else {
-                    forward = true;
-                }
-                if (!forward) {
-                    // the cell's block: header and the list's first two entries in one 128-byte line
-                    const uint4 none = make_uint4(0x7F800000u, 0u, 0u, 0u); // key +inf
-                    uint4 hd = make_uint4(0u, 0u, 0x7F800000u, 0u), q0 = none, q1 = none, q2 = none;
-                    const uint4* __restrict__ blk = g.blocks + (size_t)(cell == 0xFFFFFFFFu ? 0u : cell) * RT_SG_BLOCK_QUADS;
-                    if (cell != 0xFFFFFFFFu) {
-                        hd = blk[0];
-                        q0 = blk[1], q1 = blk[2], q2 = blk[3];
-                        RT_KEEP4(hd);
-                        RT_KEEP4(q0);
-                        RT_KEEP4(q1);
-                        RT_KEEP4(q2);
-                    }
-                    const uint32_t count = hd.x;
-                    if (count > g.heavy) {
-                        forward = true;
-                    } else {
-                        const uint4* __restrict__ ovf = g.overflow; // 48-byte entries: {key, v0} {e1, e2.x} {e2.yz, record, 0}
-                        // triangles too close to the light for a bounded dilation: tested by every segment of the light (normally none)
-                        bool occluded = false;
-                        for (uint32_t k = g.near_begin; k < g.near_end && !occluded; k++) {
-                            const uint4 n0 = ovf[3 * (size_t)k], n1 = ovf[3 * (size_t)k + 1], n2 = ovf[3 * (size_t)k + 2];
-                            if (COUNT) n_tests++;
-                            float t;
-                            occluded = moller_trumbore(v3(__uint_as_float(n0.y), __uint_as_float(n0.z), __uint_as_float(n0.w)),
-                                                       v3(__uint_as_float(n1.x), __uint_as_float(n1.y), __uint_as_float(n1.z)),
-                                                       v3(__uint_as_float(n1.w), __uint_as_float(n2.x), __uint_as_float(n2.y)), o, d, t) &&
-                                       t > RT_MIN_RAY_DISTANCE && t < dist;
-                        }
-                        bool visible = false;
-                        if (!occluded) {
-                            if (count == 0u) q0 = none;
-                            for (uint32_t i = 0;; i++) { // entry i is in q0..q2 (its key only, from the header, when i == 2 comes up)
-                                if (i >= count || !(__uint_as_float(q0.x) < limit)) { // every later triangle lies beyond the segment's end
-                                    visible = true;
-                                    break;
-                                }
-                                if (i == RT_WF_GRID_WALK) {
-                                    forward = true;
-                                    break;
-                                }
-                                if (i == RT_SG_BLOCK_ENTRIES) { // the first entry beyond the block is fetched only now that its key (header) says it is needed
-                                    const size_t at = 3 * (size_t)hd.y;
-                                    q0 = ovf[at], q1 = ovf[at + 1], q2 = ovf[at + 2];
-                                }
-                                if (COUNT) n_entries++, n_tests++;
-                                float t;
-                                // the acceptance of test_triangle for a segment that has hit nothing yet: 1e-5 < t < its length
-                                if (moller_trumbore(v3(__uint_as_float(q0.y), __uint_as_float(q0.z), __uint_as_float(q0.w)),
-                                                    v3(__uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z)),
-                                                    v3(__uint_as_float(q1.w), __uint_as_float(q2.x), __uint_as_float(q2.y)), o, d, t) &&
-                                    t > RT_MIN_RAY_DISTANCE && t < dist)
-                                    break; // occluded
-                                // the next entry: the second of the block (same line); of the third only the key (it is in the header); later
-                                // ones whole (they follow the third in the overflow array)
-                                const uint32_t nx = i + 1u;
-                                q0 = none;
-                                if (nx < count) {
-                                    if (nx < RT_SG_BLOCK_ENTRIES) q0 = blk[4], q1 = blk[5], q2 = blk[6];
-                                    else if (nx == RT_SG_BLOCK_ENTRIES) q0.x = hd.z;
-                                    else {
-                                        const size_t at = 3 * (size_t)(hd.y + (nx - RT_SG_BLOCK_ENTRIES));
-                                        q0 = ovf[at], q1 = ovf[at + 1], q2 = ovf[at + 2];
-                                    }
-                                }
-                            }
-                        }
-                        if (visible) atomicOr(reinterpret_cast<uint32_t*>(&wb.vtx[2 * (size_t)id + 1]) + 3, 1u << li);
-                        if (COUNT && !forward) n_answered++;
-                    }
-                }
-            }
+            point = f4v(vp), normal = f4v(vn);
+            if (__float_as_uint(vp.w) != 0xFFFFFFFFu) want = __float_as_uint(vn.w); // ("no vertex": the path ended in k_wf_shade)
         }
-        // hand on: collected per wave in LDS and appended 64 or more at a time (one atomic on the queue's counter per append:
-        // an atomic per wave and iteration, 1.5 M of them on one address, cost more than the whole list walk)
-        const unsigned long long fm = __ballot(forward);
-        if (fm != 0ull) {
-            if (forward) s_fwd[wave][n_fwd + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull))] = e;
-            n_fwd += (uint32_t)__popcll(fm);
-            if (n_fwd >= 64u) {
-                uint32_t at = 0;
-                if (lane == 0) at = atomicAdd(&wb.counters[rt::WF_SHADOW2_COUNT], n_fwd);
-                at = __shfl(at, 0, WAVE);
-                for (uint32_t k = lane; k < n_fwd; k += WAVE) wb.q_shadow2[at + k] = s_fwd[wave][k];
-                n_fwd = 0;
+        uint32_t occluded = 0;
+        for (uint32_t li = 0; li < sc.n_lights; li++) {
+            const bool mine = (want >> li) & 1u;
+            if (__ballot(mine) == 0ull) continue;
+            uint32_t outcome = GRID_VISIBLE;
+            GridPending pd = {};
+            if (mine) {
+                outcome = grid_segment_head<COUNT>(sc, s_lights[li], s_grids[li], point, normal, pd, n_tests, n_entries);
+                if (outcome == GRID_OCCLUDED) occluded |= 1u << li;
+                if (COUNT && outcome <= GRID_OCCLUDED) n_answered++;
             }
+            const uint32_t entry = id | (li << 27);
+            park_push(mine && outcome == GRID_PENDING, pd, entry);
+            hand_on(mine && outcome == GRID_FORWARD, entry, false);
+            while (n_park >= 64u) walk_parked(); // (a pass parks again what it leaves undecided: below 64 before the next light adds its own)
         }
+        if (occluded != 0u) atomicAnd(reinterpret_cast<uint32_t*>(&wb.vtx[2 * (size_t)id + 1]) + 3, ~occluded);
     }
-    if (n_fwd) {
-        uint32_t at = 0;
-        if (lane == 0) at = atomicAdd(&wb.counters[rt::WF_SHADOW2_COUNT], n_fwd);
-        at = __shfl(at, 0, WAVE);
-        for (uint32_t k = lane; k < n_fwd; k += WAVE) wb.q_shadow2[at + k] = s_fwd[wave][k];
-    }
+    while (n_park != 0u) walk_parked();
+    hand_on(false, 0u, true);
     if (COUNT) {
         const unsigned long long t = wave_sum(n_tests), a = wave_sum(n_answered), en = wave_sum(n_entries);
         if ((threadIdx.x & 63u) == 0) {
@@ -974,6 +1060,9 @@ __global__ __launch_bounds__(256, RT_WF_SHADE_WAVES) void k_wf_shade(DevScene sc
     stage_lights(s_lights, sc);
     const uint32_t count = wb.counters[rt::WF_EXT_COUNT];
     const bool shadows = (fr.flags & 2u) == 0;
+    // with light grids the shadow stage works per vertex (k_wf_shadow_grid): the lights that need a segment go into the vertex record's
+    // visibility word as a mask, not into the shadow queue as entries
+    const bool to_grids = shadows && wb.grids != nullptr;
     const uint32_t stride = gridDim.x * blockDim.x;
     OutWindow win = {0u, 0u};
     uint32_t n_shadow = 0;
@@ -1007,7 +1096,7 @@ __global__ __launch_bounds__(256, RT_WF_SHADE_WAVES) void k_wf_shade(DevScene sc
                     vertex = true;
                     m = load_material(sc, material_id);
                     wb.vtx[2 * (size_t)id] = make_float4(point.x, point.y, point.z, __uint_as_float(material_id));
-                    wb.vtx[2 * (size_t)id + 1] = make_float4(normal.x, normal.y, normal.z, 0.0f);
+                    if (!shadows) wb.vtx[2 * (size_t)id + 1] = make_float4(normal.x, normal.y, normal.z, 0.0f);
                 }
             }
         }
@@ -1023,6 +1112,12 @@ __global__ __launch_bounds__(256, RT_WF_SHADE_WAVES) void k_wf_shade(DevScene sc
                     const V3 contrib = light_contribution(s_lights[li], m, point, normal, sdir, sdist);
                     if (contrib.x != 0.0f || contrib.y != 0.0f || contrib.z != 0.0f) mask |= 1u << li;
                 }
+            }
+            // the visibility word of the vertex record starts as this mask; the shadow stage clears the bits of occluded segments
+            if (vertex) wb.vtx[2 * (size_t)id + 1] = make_float4(normal.x, normal.y, normal.z, __uint_as_float(mask));
+            if (to_grids) { // (k_wf_shadow_grid goes by vertex, not by queue entry)
+                n_shadow += (uint32_t)__popc(mask);
+                continue;
             }
 #if RT_WF_SHADOW_LIGHT_MAJOR
             // light-major order inside the wave's slice: consecutive entries (one traversal wave's refill) go
@@ -1112,7 +1207,7 @@ __global__ __launch_bounds__(256, RT_WF_SHADE_WAVES) void k_wf_finish(DevScene s
             RT_KEEP4(ra);
             RT_KEEP4(rdin);
         }
-        const uint32_t vis = __float_as_uint(vn.w); // one bit per light, set by the shadow stage
+        const uint32_t vis = __float_as_uint(vn.w); // one bit per light: k_wf_shade's mask of lights with a segment, less those the shadow stage found occluded
         if (__float_as_uint(vp.w) != 0xFFFFFFFFu) { // paths that ended in k_wf_shade carry the "no vertex" marker
             const V3 point = f4v(vp), normal = f4v(vn);
             const uint32_t material_id = __float_as_uint(vp.w);
@@ -1338,8 +1433,8 @@ hipError_t wf_bounce(const DevScene& sc, const DevFrame& fr, const WfBuffers& wb
         if (wb.grids) { // the light grids answer what they can and hand the rest on to the traversal
             const dim3 ggrid((uint32_t)(cu_count() * RT_WF_GRID_BLOCKS_PER_CU));
             if (grid_events) (void)hipEventRecord(grid_events[0], s);
-            if (counters) hipLaunchKernelGGL(k_wf_shadow_grid<true>, ggrid, dim3(256), 0, s, sc, wb);
-            else hipLaunchKernelGGL(k_wf_shadow_grid<false>, ggrid, dim3(256), 0, s, sc, wb);
+            if (counters) hipLaunchKernelGGL(k_wf_shadow_grid<true>, ggrid, dim3(256), 0, s, sc, wb, (const uint32_t*)cur_q);
+            else hipLaunchKernelGGL(k_wf_shadow_grid<false>, ggrid, dim3(256), 0, s, sc, wb, (const uint32_t*)cur_q);
             if (grid_events) (void)hipEventRecord(grid_events[1], s);
             if (counters) launch_trace<true, true>(sc, wb, wb.q_shadow2, WF_SHADOW2_COUNT, WF_SHADOW2_CURSOR, WF_SHADOW2_WINDOW, s);
             else launch_trace<false, true>(sc, wb, wb.q_shadow2, WF_SHADOW2_COUNT, WF_SHADOW2_CURSOR, WF_SHADOW2_WINDOW, s);
