@@ -61,14 +61,16 @@ static_assert(sizeof(DevShadowGrid) == 128, "DevShadowGrid is staged in LDS and 
 #define RT_SG_ENTRY_QUADS 3u
 #define RT_SG_BLOCK_QUADS 8u   /* 128 bytes per cell */
 #define RT_SG_BLOCK_ENTRIES 2u /* entries held in the cell's own block */
-#define RT_SG_SORTED_PREFIX 16u /* a list's first 16 entries are its 16 nearest in order; later ones follow unordered (a walk gives up before them) */
+#ifndef RT_SG_SORTED_PREFIX
+#define RT_SG_SORTED_PREFIX 32u /* a list's first 32 entries are its 32 nearest in order; later ones follow unordered (a walk gives up before them) */
+#endif
 
 namespace rt {
 
 struct ShadowGridOptions {
     uint32_t res_point = 1024;   // cells per side of a cube face
     uint32_t res_dir = 2048;     // cells per side of an orthographic grid
-    uint32_t heavy = 64;         // longest list a segment walks itself
+    uint32_t heavy = 128;        // longest list a segment walks itself (its nearest RT_SG_SORTED_PREFIX - 1 entries at most); 64 until the end of round 3
     uint64_t max_entries = 400ull << 20; // per light; beyond it the light gets no grid
     uint64_t max_bytes = ~0ull;  // per light, cell blocks + list entries; a grid that would take more is refused (before anything of it is allocated)
     double max_mean_list = 9.0;  // entries per filled cell ...

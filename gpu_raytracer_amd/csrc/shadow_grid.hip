@@ -472,7 +472,7 @@ hipError_t shadow_grid_build(const DevTri* d_tris, uint32_t n_records, const Dev
     // third of the segments handed on after walking a list for nothing) loses against the BVH, and such a light gets no grid.
     const bool long_lists = (double)total > opt.max_mean_list * (double)std::max<uint64_t>(1, sums[1]) || (double)sums[2] > opt.max_heavy_share * (double)sums[1];
     // (total bounds the overflow entries, so the 32-bit scan above did not wrap when it is accepted here)
-    if (total == 0 || total > std::min<uint64_t>(opt.max_entries, 0xFFFFFFFFull / RT_SG_ENTRY_QUADS) || near_count > opt.heavy || long_lists) {
+    if (total == 0 || total > std::min<uint64_t>(opt.max_entries, 0xFFFFFFFFull / RT_SG_ENTRY_QUADS) || near_count > std::min(opt.heavy, 64u) || long_lists) {
         cleanup();
         return hipSuccess; // no grid for this light
     }

@@ -780,7 +780,7 @@ __device__ __forceinline__ DevMaterial load_material(const DevScene& sc, uint32_
 // appended, densely, to q_shadow2 for k_wf_trace<any hit>.
 // ---------------------------------------------------------------------------------------------------------
 #ifndef RT_WF_GRID_WALK
-#define RT_WF_GRID_WALK 15 /* entries a segment looks at before it is handed on (12 while a long walk held its whole wave up: rounds 2-3) */
+#define RT_WF_GRID_WALK 31 /* entries a segment looks at before it is handed on (12 while a long walk held its whole wave up: rounds 2-3) */
 #endif
 static_assert(EXT_EPS == RT_SG_EXT_EPS, "the light grids' dilation is derived from the shadow segments' origin offset");
 static_assert(RT_WF_GRID_WALK < RT_SG_SORTED_PREFIX, "a walk may only look at the ordered part of a list");
