@@ -190,3 +190,37 @@ def test_slivers_and_needles(gpu_ctx):
                        H.light_directional((0.1, -0.2, -1.0), (1, 1, 1), 0.8)], dtype=T.LIGHT)
     sc = _scene("slivers", tris, list(ids) + [int(i) % 4 for i in range(n)], lights=lights)
     _same_frame(gpu_ctx, sc, 320, 240, 8, 4, min_answered=0.0)
+
+
+def test_a_fan_of_needles_takes_the_lists_through_every_regime_of_the_walk(gpu_ctx, oracle_mod):
+    """300 thin blades fanned out around the axis under a point light, over a floor: a cell on the axis has all 300 in its list, cells
+    further out ever fewer, and a segment from the floor misses nearly all of them - so the frame has lists decided inside the cell's own
+    block (<= 2 entries), lists walked on by parked segments (the wave's LDS list, several passes), walks that reach the limit
+    (RT_WF_GRID_WALK) and cells over `heavy`, both handed on to the BVH.  Same bits as the BVH walk, and as the oracle."""
+    n = 300
+    ang = np.linspace(0.0, 2 * np.pi, n, endpoint=False)
+    z = -1.0 + 2.5 * (np.arange(n) * 37 % n) / n  # heights shuffled, so that distance order and angle order differ
+    r0, r1, half = 0.0, 3.5, 0.004
+    c, s = np.cos(ang), np.sin(ang)
+    a = np.stack([r0 * c, r0 * s, z], 1)
+    b = np.stack([r1 * c - half * s, r1 * s + half * c, z], 1)
+    d = np.stack([r1 * c + half * s, r1 * s - half * c, z], 1)
+    blades = np.stack([a, b, d], 1).astype(np.float32)
+    floor, ids = _grid(12, 12, z=-3.0, size=9.0)
+    tris = np.concatenate([floor, blades])
+    lights = np.array([H.light_point((0.0, 0.0, 4.0), (1, 1, 1), 30.0), H.light_directional((0.0, 0.0, -1.0), (1, 1, 1), 0.6)], dtype=T.LIGHT)
+    cam = H.camera(position=(0.0, -6.5, 3.0), direction=(0.0, 6.5, -6.0), up=(0.0, 0.0, 1.0), fov=55.0)
+    sc = _scene("fan", tris, list(ids) + [int(i) % 4 for i in range(n)], lights=lights, camera=cam)
+    os.environ["RT_SHADOW_GRID_MEAN"] = "1e9"  # (the long lists on the axis must not make the build refuse the grids)
+    try:
+        info, use, st = _same_frame(gpu_ctx, sc, 480, 320, 8, 3, min_answered=0.3, camera=cam, expect_grids=2)
+        per_light = [gpu_ctx.debug_shadow_grid(i) for i in range(2)]
+        assert max(g["longest"] for g in per_light) > 128, per_light                           # cells over `heavy` exist ...
+        assert 0 < st["shadow_rays"] - use["segments_answered"] < 0.5 * st["shadow_rays"]       # ... and segments were handed on, and most were not
+        assert use["entries_read"] > 3.0 * use["segments_answered"]                             # walks well beyond a cell's block
+        packed = oracle_mod.PackedScene(sc, use_bvh=False)
+        ext = oracle_mod.render_extended(packed, 96, 64, 2, 2, camera=cam, frame_seed=9)
+        gpu_ctx.render(96, 64, cam, mode=2, spp=2, max_bounces=2, frame_seed=9)
+        np.testing.assert_array_equal(gpu_ctx.read_rgb32f().view(np.uint32), ext["rgb"].view(np.uint32))
+    finally:
+        del os.environ["RT_SHADOW_GRID_MEAN"]
