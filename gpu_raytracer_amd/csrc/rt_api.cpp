@@ -694,7 +694,11 @@ int run_frame(rt_ctx* ctx, DevFrame fr, bool counters, uint32_t world, uint32_t 
             const char* lanes_env = std::getenv("RT_WF_LANES"); // (read per frame: tests and A/B runs switch it)
             // by default only for frames whose shadow stage runs on light grids: with the BVH walk both big stages are VALU-bound and sharing
             // the chip gains nothing (bistro-like 4K share: 136.7 ms on two lanes against 127.3 on one)
-            const bool two_lanes_on = lanes_env ? std::atoi(lanes_env) >= 2 : (RT_WF_LANES_DEFAULT >= 2 && d.grids != nullptr && !(f.flags & RT_FLAG_NO_SHADOW_GRID));
+            bool two_lanes_on = lanes_env ? std::atoi(lanes_env) >= 2 : (RT_WF_LANES_DEFAULT >= 2 && d.grids != nullptr && !(f.flags & RT_FLAG_NO_SHADOW_GRID));
+            // ... and not for a frame of long paths that fits ONE batch: two lanes would cut it in two, every launch would come twice, and
+            // beyond four bounces most launches serve few paths and cost their latency whatever they serve (bistro-like 4K share, 64 spp,
+            // 8 bounces, 66 M paths: one batch on one lane 105.3 ms, two of 32 samples on two lanes 116.7; 4 bounces: the two lanes win)
+            if (!lanes_env && two_lanes_on && f.max_bounce > 4 && wavefront_batch(n_blocks, f.spp, ctx->scene_counts.n_lights, free_b, false) >= f.spp) two_lanes_on = false;
             const uint32_t batch = d.wf.n_blocks == n_blocks && d.wf_spp == f.spp && d.wf.batch && d.wf_lights >= ctx->scene_counts.n_lights && d.used_two_lanes == (two_lanes_on && f.spp >= 2) ? d.wf.batch // same frame shape as last time: keep the allocation
                                                                                                : wavefront_batch(n_blocks, f.spp, ctx->scene_counts.n_lights, two_lanes_on ? free_b / 2 : free_b, two_lanes_on);
             d.wf_spp = f.spp;

@@ -73,8 +73,8 @@ struct ShadowGridOptions {
     uint32_t heavy = 128;        // longest list a segment walks itself (its nearest RT_SG_SORTED_PREFIX - 1 entries at most); 64 until the end of round 3
     uint64_t max_entries = 400ull << 20; // per light; beyond it the light gets no grid
     uint64_t max_bytes = ~0ull;  // per light, cell blocks + list entries; a grid that would take more is refused (before anything of it is allocated)
-    double max_mean_list = 9.0;  // entries per filled cell ...
-    double max_heavy_share = 0.01; // ... and share of cells over `heavy` beyond which a grid does not pay (shadow_grid.hip)
+    double max_mean_list = 32.0; // entries per filled cell ... (9 and 1 % until the end of round 3: no grids for cluttered scenes then)
+    double max_heavy_share = 0.05; // ... and share of cells over `heavy` beyond which a grid does not pay (shadow_grid.hip)
 };
 
 struct ShadowGridBuild {

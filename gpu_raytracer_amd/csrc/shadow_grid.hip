@@ -334,6 +334,25 @@ __global__ __launch_bounds__(256) void k_sg_sort(const uint32_t* __restrict__ co
     if (c < n_cells) blk[0] = make_uint4(n, os, n > RT_SG_BLOCK_ENTRIES ? at(RT_SG_BLOCK_ENTRIES)[0].x : 0x7F800000u, 0u);
 }
 
+// What a walk can ever look at: a list's nearest RT_SG_SORTED_PREFIX entries when it has at most `heavy` (a walk gives up before the
+// unordered rest), nothing of a longer one (its segments are handed to the BVH unseen); the near list whole.  Beyond the cell's block.
+__global__ __launch_bounds__(256) void k_sg_keep(const uint32_t* __restrict__ count, uint32_t* __restrict__ keep, uint32_t n_cells, uint32_t heavy) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > n_cells) return;
+    const uint32_t n = count[c];
+    const uint32_t looked_at = n <= heavy ? (n < RT_SG_SORTED_PREFIX ? n : RT_SG_SORTED_PREFIX) : 0u;
+    keep[c] = c < n_cells ? (looked_at > RT_SG_BLOCK_ENTRIES ? looked_at - RT_SG_BLOCK_ENTRIES : 0u) : n;
+}
+// ... moved from the array the lists were built in (every entry rasterised) to the one the frames read; the headers follow
+__global__ __launch_bounds__(256) void k_sg_compact(const uint32_t* __restrict__ keep, const uint32_t* __restrict__ keep_start, const uint32_t* __restrict__ ovf_start,
+                                                    const uint4* __restrict__ built, uint4* __restrict__ overflow, uint4* __restrict__ blocks, uint32_t n_cells) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > n_cells) return;
+    const uint32_t n = keep[c], from = ovf_start[c], to = keep_start[c];
+    for (uint32_t q = 0; q < n * RT_SG_ENTRY_QUADS; q++) overflow[(size_t)to * RT_SG_ENTRY_QUADS + q] = built[(size_t)from * RT_SG_ENTRY_QUADS + q];
+    if (c < n_cells) reinterpret_cast<uint32_t*>(blocks + (size_t)c * RT_SG_BLOCK_QUADS)[1] = to;
+}
+
 #define SG_CHK(call)                  \
     do {                              \
         hipError_t e_ = (call);       \
@@ -423,24 +442,29 @@ hipError_t shadow_grid_build(const DevTri* d_tris, uint32_t n_records, const Dev
         limit_margin = (float)(2.0 * eps_eff + 1.0e-5 * d_max);
     }
 
-    uint32_t *count = nullptr, *ovf = nullptr, *ovf_start = nullptr, *stats = nullptr;
+    uint32_t *count = nullptr, *ovf = nullptr, *ovf_start = nullptr, *keep = nullptr, *keep_start = nullptr, *stats = nullptr;
     unsigned long long* total64 = nullptr;
-    uint4 *blocks = nullptr, *overflow = nullptr;
+    uint4 *blocks = nullptr, *overflow = nullptr, *built = nullptr;
     void* temp = nullptr;
     auto cleanup = [&]() {
         (void)hipFree(count);
         (void)hipFree(ovf);
         (void)hipFree(ovf_start);
+        (void)hipFree(keep);
+        (void)hipFree(keep_start);
         (void)hipFree(stats);
         (void)hipFree(total64);
         (void)hipFree(blocks);
         (void)hipFree(overflow);
+        (void)hipFree(built);
         (void)hipFree(temp);
     };
     const size_t lists = (size_t)p.n_cells + 1; // + the near list
     SG_CHK(hipMalloc((void**)&count, lists * 4));
     SG_CHK(hipMalloc((void**)&ovf, lists * 4));
     SG_CHK(hipMalloc((void**)&ovf_start, (lists + 1) * 4));
+    SG_CHK(hipMalloc((void**)&keep, lists * 4));
+    SG_CHK(hipMalloc((void**)&keep_start, (lists + 1) * 4));
     SG_CHK(hipMalloc((void**)&stats, 2 * 4));
     SG_CHK(hipMalloc((void**)&total64, 3 * 8));
     SG_CHK(hipMemsetAsync(total64, 0, 3 * 8, stream));
@@ -457,19 +481,25 @@ hipError_t shadow_grid_build(const DevTri* d_tris, uint32_t n_records, const Dev
     SG_CHK(hipMalloc(&temp, temp_bytes ? temp_bytes : 16));
     SG_CHK(rocprim::exclusive_scan(temp, temp_bytes, ovf, ovf_start, 0u, lists, rocprim::plus<uint32_t>(), stream));
     hipLaunchKernelGGL(k_sg_total, dim3(1), dim3(1), 0, stream, ovf_start, ovf, (uint32_t)(lists - 1));
-    uint32_t tail[2] = {0, 0}; // [start of the near list, all overflow entries]
+    hipLaunchKernelGGL(k_sg_keep, dim3((uint32_t)((lists + 255) / 256)), dim3(256), 0, stream, count, keep, p.n_cells, opt.heavy);
+    SG_CHK(rocprim::exclusive_scan(temp, temp_bytes, keep, keep_start, 0u, lists, rocprim::plus<uint32_t>(), stream)); // (same size and types as the scan above)
+    hipLaunchKernelGGL(k_sg_total, dim3(1), dim3(1), 0, stream, keep_start, keep, (uint32_t)(lists - 1));
+    uint32_t tail[2] = {0, 0}, built_tail[2] = {0, 0}; // [start of the near list, all overflow entries]: kept for the frames / as built
     unsigned long long sums[3] = {0, 0, 0};
-    SG_CHK(hipMemcpyAsync(tail, ovf_start + lists - 1, 8, hipMemcpyDeviceToHost, stream));
+    SG_CHK(hipMemcpyAsync(tail, keep_start + lists - 1, 8, hipMemcpyDeviceToHost, stream));
+    SG_CHK(hipMemcpyAsync(built_tail, ovf_start + lists - 1, 8, hipMemcpyDeviceToHost, stream));
     SG_CHK(hipMemcpyAsync(sums, total64, 3 * 8, hipMemcpyDeviceToHost, stream));
     SG_CHK(hipStreamSynchronize(stream));
     const unsigned long long total = sums[0];
     out->n_entries = total;
     out->filled_cells = (uint32_t)sums[1];
     out->heavy_cells = (uint32_t)sums[2];
-    const uint32_t near_count = tail[1] - tail[0];
-    // A grid pays when its lists are short: 2.2 entries read per segment on the sponza-like scene (4 - 7 triangles per filled cell, one
-    // cell in a thousand over `heavy`) against 11 node visits of the BVH; foliage-like clutter (bistro-like: 14 per cell, 4 % heavy, a
-    // third of the segments handed on after walking a list for nothing) loses against the BVH, and such a light gets no grid.
+    const uint32_t near_count = tail[1] - tail[0]; // (kept whole)
+    // A grid pays when its lists are short: 2.3 entries read per segment on the sponza-like scene (4 - 7 triangles per filled cell, one
+    // cell in a thousand over 64 entries) against 11 node visits of the BVH.  Foliage-like clutter (bistro-like: 14 per filled cell, 4 % of
+    // the cells over 64) lost against the BVH while a long walk held its whole wave up (rounds 2-3); with the walks parked
+    // (k_wf_shadow_grid) and the lists cut to what a walk looks at, that scene's lights answer 81 % of their segments from the lists,
+    // 6 entries each, and the frame is 12 % faster.  Refused now: lists beyond that kind of clutter.
     const bool long_lists = (double)total > opt.max_mean_list * (double)std::max<uint64_t>(1, sums[1]) || (double)sums[2] > opt.max_heavy_share * (double)sums[1];
     // (total bounds the overflow entries, so the 32-bit scan above did not wrap when it is accepted here)
     if (total == 0 || total > std::min<uint64_t>(opt.max_entries, 0xFFFFFFFFull / RT_SG_ENTRY_QUADS) || near_count > std::min(opt.heavy, 64u) || long_lists) {
@@ -481,26 +511,40 @@ hipError_t shadow_grid_build(const DevTri* d_tris, uint32_t n_records, const Dev
         cleanup();
         return hipSuccess;
     }
+    // The lists are built whole (every entry rasterised: the nearest ones of a list are only known once it is complete) in an array that
+    // lives for the build; what the frames read is what a walk can look at.  On cluttered scenes that is a fraction - the bistro-like
+    // scene's lights: 256 M entries rasterised, most of them deep in long lists.
     SG_CHK(hipMalloc((void**)&blocks, block_bytes));
-    SG_CHK(hipMalloc((void**)&overflow, ovf_bytes));
+    SG_CHK(hipMalloc((void**)&built, ((size_t)built_tail[1] + 1) * RT_SG_ENTRY_QUADS * sizeof(uint4)));
     SG_CHK(hipMemsetAsync(blocks, 0, block_bytes, stream)); // (an untouched cell is an empty list)
     SG_CHK(hipMemsetAsync(count, 0, lists * 4, stream));
     p.ovf_start = ovf_start;
     p.blocks = blocks;
-    p.overflow = overflow;
+    p.overflow = built;
     hipLaunchKernelGGL(k_sg_raster<true>, grid, block, 0, stream, p);
     SG_CHK(hipGetLastError());
-    hipLaunchKernelGGL(k_sg_sort, dim3((uint32_t)((lists + 255) / 256)), dim3(256), 0, stream, count, ovf_start, blocks, overflow, p.n_cells, opt.heavy, stats);
+    hipLaunchKernelGGL(k_sg_sort, dim3((uint32_t)((lists + 255) / 256)), dim3(256), 0, stream, count, ovf_start, blocks, built, p.n_cells, opt.heavy, stats);
     SG_CHK(hipGetLastError());
+    if (tail[1] == built_tail[1]) { // nothing to leave out
+        overflow = built;
+        built = nullptr;
+    } else {
+        SG_CHK(hipMalloc((void**)&overflow, ovf_bytes));
+        hipLaunchKernelGGL(k_sg_compact, dim3((uint32_t)((lists + 255) / 256)), dim3(256), 0, stream, keep, keep_start, ovf_start, built, overflow, blocks, p.n_cells);
+        SG_CHK(hipGetLastError());
+    }
     uint32_t st[2] = {0, 0};
     SG_CHK(hipMemcpyAsync(st, stats, 8, hipMemcpyDeviceToHost, stream));
     SG_CHK(hipStreamSynchronize(stream));
     (void)hipFree(count);
     (void)hipFree(ovf);
     (void)hipFree(ovf_start);
+    (void)hipFree(keep);
+    (void)hipFree(keep_start);
     (void)hipFree(stats);
     (void)hipFree(total64);
     (void)hipFree(temp);
+    (void)hipFree(built);
 
     DevShadowGrid& g = out->grid;
     g.kind = p.kind;

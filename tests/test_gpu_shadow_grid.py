@@ -53,14 +53,20 @@ def test_sponza_like_every_light_has_a_grid(gpu_ctx):
     assert use["entries_read"] < 4 * use["segments_answered"]  # short lists are the point (2.2 per segment on the headline frame)
 
 
-def test_cluttered_scene_refuses_its_grids_and_forced_grids_still_agree(gpu_ctx):
-    """bistro-like: foliage seen end-on makes long lists, the build refuses them (the BVH is faster there); forced on, the lists still
-    answer like the BVH, with a third of the segments handed on."""
+def test_cluttered_scene_lists_cut_to_what_a_walk_reads(gpu_ctx):
+    """bistro-like: foliage seen end-on makes long lists.  Until the end of round 3 the build refused such grids; now the lists are
+    stored cut to the entries a walk can look at (the nearest RT_SG_SORTED_PREFIX of a list, nothing of a list over `heavy`), the lights
+    keep their grids, and the lists still answer like the BVH, with a part of the segments handed on."""
     sc = scenes.bistro_like(n_triangles=1200000)
-    _same_frame(gpu_ctx, sc, 320, 180, 2, 3)
-    os.environ["RT_SHADOW_GRID_MEAN"] = "1e9"
+    info, use, st = _same_frame(gpu_ctx, sc, 320, 180, 2, 3, min_answered=0.2, expect_grids=len(sc.lights))
+    per_light = [gpu_ctx.debug_shadow_grid(i) for i in range(len(sc.lights))]
+    assert max(g["longest"] for g in per_light) > 128                                  # there are lists over `heavy` ...
+    block_bytes = sum((6 if g["kind"] == 1 else 1) * g["res"] ** 2 * 128 for g in per_light)
+    assert info["bytes"] - block_bytes < 0.9 * 48 * info["entries"]                    # ... and the grids hold fewer entries than were rasterised
+    assert 0 < st["shadow_rays"] - use["segments_answered"] < 0.6 * st["shadow_rays"]
+    os.environ["RT_SHADOW_GRID_MEAN"] = "1e9"  # (the acceptance rule out of the way: the same lists)
     try:
-        info, use, st = _same_frame(gpu_ctx, sc, 320, 180, 2, 3, min_answered=0.2, expect_grids=len(sc.lights))
+        _same_frame(gpu_ctx, sc, 320, 180, 2, 3, min_answered=0.2, expect_grids=len(sc.lights))
     finally:
         del os.environ["RT_SHADOW_GRID_MEAN"]
 
