@@ -59,6 +59,7 @@ struct DeviceState {
     std::vector<void*> grid_allocs;
     std::vector<rt::ShadowGridBuild> grid_info;
     bool grids_tried = false;                              // the light grids of the current scene were built (or refused) on this device
+    bool grids_partial = false;                            // ... and a light that has triangles to cast shadows was left without one: then no light keeps its grid
     rt::WfBuffers wf{};                                    // wavefront pipeline state (extended mode)
     rt::WfBuffers wf2{};                                   // ... of the second lane (its own path state, queues and counters; the pixel sums are shared)
     std::vector<void*> wf2_allocs;
@@ -135,6 +136,7 @@ void free_scene(DeviceState& d) {
     d.grid_info.clear();
     d.grids = nullptr;
     d.grids_tried = false;
+    d.grids_partial = false;
 }
 void free_targets(DeviceState& d) {
     (void)hipSetDevice(d.device);
@@ -480,7 +482,24 @@ int ensure_grids(rt_ctx* ctx, DeviceState& d) {
         if (gb.overflow) d.grid_allocs.push_back(gb.overflow);
         if (gb.grid.kind != RT_SG_KIND_NONE) bytes += gb.bytes;
         any = any || gb.grid.kind != RT_SG_KIND_NONE;
+        if (gb.grid.kind == RT_SG_KIND_NONE && gb.n_entries != 0) d.grids_partial = true; // lists were counted and found too long (or too large): this light's segments walk the tree
         d.grid_info.push_back(gb);
+    }
+    if (any && d.grids_partial) {
+        // All lights or none.  The segments of a light without a grid are handed on one wave-load at a time, an atomic on the next queue's
+        // counter each: a trickle when the lists leave 0.1 - 20 % to the tree, but with a whole light's segments it is millions of atomics
+        // on one address per frame (bistro-like with one light of four on lists: 67 - 81 ms against 54 - 60 with no grids at all).
+        HIPCHK(ctx, hipDeviceSynchronize());
+        for (void* p : d.grid_allocs) (void)hipFree(p);
+        d.grid_allocs.clear();
+        for (uint32_t i = 0; i < n_lights; i++) {
+            hg[i] = DevShadowGrid{};
+            d.grid_info[i].grid = DevShadowGrid{};
+            d.grid_info[i].blocks = d.grid_info[i].overflow = nullptr;
+            d.grid_info[i].bytes = 0;
+        }
+        any = false;
+        bytes = 0;
     }
     if (any) {
         int rc;
@@ -1181,6 +1200,7 @@ static int prepare_quality_tree(rt_ctx* ctx) {
         d.grid_info.clear();
         d.grids = nullptr;
         d.grids_tried = false;
+        d.grids_partial = false;
     }
     DevScene& sc = ctx->scene_counts;
     sc.n_nodes = (uint32_t)bvh.nodes.size();
