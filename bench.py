@@ -415,7 +415,7 @@ def main():
                 "achieved_source": "algorithmic bytes per launch (counting variant of the same kernels, this run) / average duration of the kernel's launches, HIP events on "
                                    "their stream, frames on one lane (this run); traffic: FETCH_SIZE x 1 + WRITE_SIZE of the committed PMC passes of this build - its reads are "
                                    "scattered 16-byte quads, for which FETCH_SIZE counts requests of 64 bytes (profiles/r03_fetch_calibration.json)",
-                "practical_bound": "the rate of scattered memory requests (33 G/s of 64 bytes against 24-43 G/s that a bare gather loop sustains, profiles/r03_fetch_calibration.json): "
+                "practical_bound": "the rate of scattered memory requests (37 G/s of 64 bytes against 24-43 G/s that a bare gather loop sustains, profiles/r03_fetch_calibration.json): "
                                    "every segment costs its cell's block and 0.5 further entries, none of it shared between neighbouring lanes beyond depth 0; fewer requests "
                                    "per segment (packed cell blocks), more requests in flight (the next light's block fetched while this one's is looked at) and more waves "
                                    "all measured no faster (profiles/ab_r03.json)",
