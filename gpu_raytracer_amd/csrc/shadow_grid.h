@@ -14,8 +14,9 @@
 // (shadow_grid.hip), triangles too close to the light for that go to a "near" list every segment of the light tests, and
 // a light whose near list would be long (or whose geometry is not finite) simply has no grid.  Cells with more than
 // `heavy` triangles (foliage-like clutter seen end-on) and lights without a grid hand their segments on to the BVH
-// traversal kernel, and so do segments still undecided after a dozen entries.  A grid only pays when its lists are short: the build
-// measures them and refuses the grid otherwise (shadow_grid.hip).  tests/test_gpu_shadow_grid.py renders every kind of scene and
+// traversal kernel, and so do segments still undecided after RT_SG_SORTED_PREFIX - 1 entries; what a grid stores of a list is what such
+// a walk can look at.  A grid only pays when its lists are not too long: the build measures them and refuses the grid otherwise
+// (shadow_grid.hip), and a scene keeps its grids only when every light that casts shadows has one (rt_api.cpp).  tests/test_gpu_shadow_grid.py renders every kind of scene and
 // light placement with the lists and with RT_FLAG_NO_SHADOW_GRID and asks for equal bits; the oracle parity tests run on the lists.
 #ifndef RT_SHADOW_GRID_H
 #define RT_SHADOW_GRID_H

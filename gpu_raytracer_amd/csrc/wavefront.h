@@ -44,12 +44,12 @@ struct WfBuffers {
     float4* rad;         // xyz radiance of the sample so far, w = bits: rng state
     float4* vtx;         // two per path, always used together, so one 32-byte record = one cache line per gather:
                          //   [2 id]     xyz vertex position, w = bits: material id
-                         //   [2 id + 1] xyz geometric normal, w = bits: light li is visible from the current vertex (set by the shadow stage)
+                         //   [2 id + 1] xyz geometric normal, w = bits: the lights with a shadow segment from the current vertex (k_wf_shade), less those the shadow stage found occluded
     float4* sample_rad;  // xyz final radiance of the sample (written when the path ends)
     uint32_t* pxy;       // x | y << 16, 0xFFFFFFFF = no pixel (tile edge)
     // queues
     uint32_t* q_ext[2];  // path ids to extend (double buffered)
-    uint32_t* q_shadow;  // path id | light << 27
+    uint32_t* q_shadow;  // path id | light << 27 (frames without light grids; with them the shadow stage goes by vertex, over q_ext)
     uint32_t* q_shadow2; // the same entries, those the light grids (shadow_grid.h) leave to the BVH; dense
     const DevShadowGrid* grids; // one per light, or null: every shadow segment walks the BVH
     uint32_t* counters;  // WfCounter

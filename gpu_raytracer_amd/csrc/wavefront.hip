@@ -789,8 +789,10 @@ static_assert(RT_WF_GRID_WALK < RT_SG_SORTED_PREFIX, "a walk may only look at th
                                         headline frame, an eighth of it +0.4 % / +2 % / +2 % (round 3, profiles/ab_r03.json) */
 #endif
 #ifndef RT_WF_GRID_MIN_WAVES
-#define RT_WF_GRID_MIN_WAVES 7 /* waves per SIMD the list walk is register-allocated for: 8 (64 VGPRs) spills five registers inside its loop - scratch
-                                traffic in a stage bound by memory requests; 7 (72 VGPRs): -2.7 % on the headline frame, 6 the same (profiles/ab_r03.json) */
+#define RT_WF_GRID_MIN_WAVES 7 /* waves per SIMD asked of the register allocator.  By segment (rounds 2-3): 8 (64 VGPRs) spilled five registers inside the
+                                loop - scratch traffic in a stage bound by memory requests; 7 (72 VGPRs): -2.7 % on the headline frame, 6 the same.  By vertex
+                                the block's 30 KB of LDS (the parking lists) allow five blocks per CU, the compiler knows it and takes 86 VGPRs, no spills;
+                                5, 6 and 7 waves had measured the same before (profiles/ab_r03.json) */
 #endif
 // One shadow segment (vertex `point` / `normal` toward light li) against the head of its cell's list: what the cell's own 128-byte block
 // holds (header, two entries, the key of the third).  Outcome GRID_VISIBLE / GRID_OCCLUDED / GRID_FORWARD (left to the BVH), or
